@@ -1,0 +1,390 @@
+"""Scene catalogue shared by the golden-vector generator and the parity tests.
+
+A scene is a declarative description of a simulation written against the
+user-level API that the reference and the engine under test share
+(``grid[key] = Thing(...)``).  Three builders turn it into something runnable:
+
+* ``build_api(scene, fdtd_module)``  -- for any module that exposes the fdtd
+  API: the real reference (only inside ``tests/golden/make_golden.py``) or the
+  engine under test (``fdtd_amd``).
+* ``resolve(scene, grid)``           -- reads back, from a grid built through the
+  API, the integer coordinates every component ended up with.
+* ``build_oracle(resolved)``         -- builds the numpy oracle from those integers.
+
+Keys use plain Python ints / floats / slices exactly as a user would write them.
+"""
+
+import json
+
+import numpy as np
+
+S = slice
+
+
+def _randpos(seed, shape, lo=1.0, hi=4.0):
+    return lo + (hi - lo) * np.random.RandomState(seed).rand(*shape)
+
+
+# fmt: off
+SCENES = {
+    # README example of the reference (README.md:137-296): 2-D, float keys.
+    "c1_readme": dict(
+        grid=dict(shape=(25e-6, 15e-6, 1)),
+        items=[
+            ("object",   (S(11, 32), S(30, 84), 0), dict(permittivity=1.7 ** 2, name="object")),
+            ("object",   (S(13e-6, 18e-6), S(5e-6, 8e-6), 0), dict(permittivity=1.5 ** 2)),
+            ("line",     (S(7.5e-6, 8.0e-6), S(11.8e-6, 13.0e-6), 0), dict(period=1550e-9 / 3e8, name="source")),
+            ("linedet",  (12e-6, S(None), 0), dict(name="detector")),
+            ("pml",      (S(0, 10), S(None), S(None)), dict(name="pml_xlow")),
+            ("pml",      (S(-10, None), S(None), S(None)), dict(name="pml_xhigh")),
+            ("pml",      (S(None), S(0, 10), S(None)), dict(name="pml_ylow")),
+            ("pml",      (S(None), S(-10, None), S(None)), dict(name="pml_yhigh")),
+        ],
+        steps=200,
+    ),
+    # 3-D, four PML faces of different thickness, point source.
+    "pml3d": dict(
+        grid=dict(shape=(24, 20, 16)),
+        items=[
+            ("pml",   (S(0, 6), S(None), S(None)), {}),
+            ("pml",   (S(-6, None), S(None), S(None)), {}),
+            ("pml",   (S(None), S(0, 5), S(None)), {}),
+            ("pml",   (S(None), S(None), S(-4, None)), {}),
+            ("point", (12, 10, 8), dict(period=10)),
+        ],
+        steps=80,
+    ),
+    # 3-D, all six faces, source close to a corner so that the corner overlaps matter.
+    "pml6": dict(
+        grid=dict(shape=(18, 17, 19), permittivity=1.3, permeability=1.1),
+        items=[
+            ("pml",   (S(None), S(None), S(0, 4)), dict(a=1e-6)),
+            ("pml",   (S(None), S(None), S(-5, None)), {}),
+            ("pml",   (S(0, 5), S(None), S(None)), {}),
+            ("pml",   (S(-4, None), S(None), S(None)), {}),
+            ("pml",   (S(None), S(0, 3), S(None)), {}),
+            ("pml",   (S(None), S(-6, None), S(None)), {}),
+            ("point", (6, 5, 6), dict(period=9, amplitude=2.0, phase_shift=0.3)),
+        ],
+        steps=70,
+    ),
+    # objects of every kind, overlapping each other and a PML, detectors of every kind.
+    "objects3d": dict(
+        grid=dict(shape=(30, 26, 22)),
+        items=[
+            ("pml",         (S(0, 4), S(None), S(None)), {}),
+            ("pml",         (S(-4, None), S(None), S(None)), {}),
+            ("pml",         (S(None), S(0, 4), S(None)), {}),
+            ("pml",         (S(None), S(-4, None), S(None)), {}),
+            ("pml",         (S(None), S(None), S(0, 4)), {}),
+            ("pml",         (S(None), S(None), S(-4, None)), {}),
+            ("anisotropic", (S(6, 12), S(6, 12), S(6, 12)), dict(permittivity=2.5), dict(offdiag_seed=0, offdiag_scale=0.05)),
+            ("absorbing",   (S(16, 22), S(7, 12), S(8, 12)), dict(permittivity=2.0, conductivity=2e4)),
+            ("object",      (S(8, 18), S(14, 20), S(5, 15)), dict(permittivity=("randpos", 3, (10, 6, 10), 2.0, 4.0))),
+            ("object",      (S(15, 20), S(17, 23), S(12, 18)), dict(permittivity=2.5)),      # overlaps the previous one and the y-high PML
+            ("absorbing",   (S(2, 7), S(3, 8), 10), dict(permittivity=1.2, conductivity=("randpos", 5, (5, 5, 1), 0.0, 5e4))),  # inside x-low PML
+            ("point",       (15, 13, 11), dict(period=11)),
+            ("linedet",     (S(5, 25), 13, 11), {}),
+            ("linedet",     (S(3, 27), S(2, 20), S(4, 18)), {}),
+            ("blockdet",    (S(14, 16), S(12, 13), S(10, 12)), {}),
+            ("currentdet",  (S(15, 16), 13, S(11, 12)), {}),
+        ],
+        steps=40,
+    ),
+    # periodic y and z, x PMLs, hard plane source polarised along z; boundaries interleaved.
+    "plane_x": dict(
+        grid=dict(shape=(22, 12, 10)),
+        items=[
+            ("periodic", (S(None), 0, S(None)), {}),
+            ("pml",      (S(0, 5), S(None), S(None)), {}),
+            ("periodic", (S(None), S(None), 0), {}),
+            ("pml",      (S(-5, None), S(None), S(None)), {}),
+            ("plane",    (8, S(None), S(None)), dict(period=12, polarization="z")),
+            ("linedet",  (S(0, 22), 3, 4), {}),
+        ],
+        steps=45,
+    ),
+    # periodic x (registered first), y/z PMLs after it, plane source on a y plane polarised x.
+    "plane_y": dict(
+        grid=dict(shape=(12, 21, 14)),
+        items=[
+            ("periodic", (0, S(None), S(None)), {}),
+            ("pml",      (S(None), S(0, 4), S(None)), {}),
+            ("pml",      (S(None), S(-4, None), S(None)), {}),
+            ("pml",      (S(None), S(None), S(0, 3)), {}),
+            ("plane",    (S(None), 9, S(None)), dict(period=13, amplitude=0.7, phase_shift=0.2, polarization="x")),
+            ("point",    (0, 12, 7), dict(period=8)),         # on the periodic low plane
+            ("point",    (11, 6, 7), dict(period=7)),         # on the periodic high plane
+        ],
+        steps=45,
+    ),
+    # periodic x and y, plane source on a z plane polarised y, partial plane.
+    "plane_z": dict(
+        grid=dict(shape=(14, 13, 20)),
+        items=[
+            ("pml",      (S(None), S(None), S(0, 4)), {}),
+            ("periodic", (S(None), -1, S(None)), {}),
+            ("pml",      (S(None), S(None), S(-4, None)), {}),
+            ("periodic", (-1, S(None), S(None)), {}),
+            ("plane",    (S(2, 12), S(3, 11), 7), dict(period=10, polarization="y")),
+            ("object",   (S(4, 9), S(0, 13), S(11, 14)), dict(permittivity=2.2)),   # touches both periodic y planes
+        ],
+        steps=45,
+    ),
+    # pulsed sources in 2-D (Nz = 1) with a periodic z boundary (self copy).
+    "pulse2d": dict(
+        grid=dict(shape=(40, 30, 1)),
+        items=[
+            ("periodic", (S(None), S(None), 0), {}),
+            ("pml",      (S(0, 6), S(None), S(None)), {}),
+            ("pml",      (S(-6, None), S(None), S(None)), {}),
+            ("line",     (S(12, 20), S(8, 20), 0), dict(period=15, pulse=True, cycle=3, hanning_dt=4.0)),
+            ("point",    (25, 15, 0), dict(period=12, pulse=True, amplitude=1.5)),
+            ("linedet",  (30, S(None), 0), {}),
+        ],
+        steps=90,
+    ),
+    # learnable_focus-like forward problem: 2-D, periodic z, anisotropic slab.
+    "focus2d": dict(
+        grid=dict(shape=(40, 40, 1)),
+        items=[
+            ("periodic",    (S(None), S(None), 0), {}),
+            ("point",       (20, 8, 0), dict(period=14)),
+            ("anisotropic", (S(10, 30), S(15, 25), S(0, 1)), dict(permittivity=2.5), dict(offdiag_seed=7, offdiag_scale=0.02)),
+        ],
+        steps=50,
+    ),
+    # 1-D line.
+    "line1d": dict(
+        grid=dict(shape=(60, 1, 1)),
+        items=[
+            ("pml",   (S(0, 8), S(None), S(None)), {}),
+            ("pml",   (S(-8, None), S(None), S(None)), {}),
+            ("point", (30, 0, 0), dict(period=20)),
+        ],
+        steps=90,
+    ),
+    # current / block detectors next to the source, as tests/test_detectors.py:91-100 of the reference.
+    "detectors": dict(
+        grid=dict(shape=(10, 10, 10), grid_spacing=100e-9),
+        items=[
+            ("currentdet", (4, 4, 4), {}),
+            ("blockdet",   (4, 4, 5), {}),
+            ("currentdet", (S(0, 1), S(0, 1), S(0, 1)), {}),      # wraps to index -1
+            ("point",      (5, 4, 4), dict(period=6)),
+        ],
+        steps=10,
+    ),
+    # half-steps driven by hand with a field poke in between, as tests/test_detectors.py:32-70.
+    "poke": dict(
+        grid=dict(shape=(10, 10, 10), grid_spacing=100e-9),
+        items=[
+            ("pml",        (S(0, 3), S(None), S(None)), {}),
+            ("absorbing",  (S(3, 5), S(3, 5), S(3, 5)), dict(permittivity=1.0, conductivity=1e9)),
+            ("currentdet", (4, 4, 4), dict(name="Dave")),
+            ("blockdet",   (S(4, 4), S(4, 4), S(4, 4)), {}),
+        ],
+        steps=60,
+        poke=dict(cell=(4, 4, 4, 2), fwhm_steps=6.0, center_steps=30.0),
+    ),
+}
+# fmt: on
+
+
+def _materialise(v):
+    if isinstance(v, tuple) and v and v[0] == "randpos":
+        return _randpos(*v[1:])
+    return v
+
+
+def poke_value(grid, poke):
+    """Gaussian pulse written into one field element between the half-steps
+    (reference tests/test_detectors.py:64-68 with waveforms.py:34-46)."""
+    from math import log, sqrt
+
+    t = grid.time_steps_passed * grid.time_step
+    fwhm = poke["fwhm_steps"] * grid.time_step
+    center = poke["center_steps"] * grid.time_step
+    sigma = fwhm / (2.0 * sqrt(2.0 * log(2)))
+    return float(np.exp(-(((t - center) ** 2.0) / (2.0 * (sigma ** 2.0)))))
+
+
+def build_api(scene, fdtd):
+    """Build the scene through the public fdtd-style API of module ``fdtd``."""
+    grid = fdtd.Grid(**scene["grid"])
+    made = []
+    for item in scene["items"]:
+        kind, key, kw = item[0], item[1], dict(item[2])
+        extra = item[3] if len(item) > 3 else {}
+        kw = {k: _materialise(v) for k, v in kw.items()}
+        cls = {
+            "pml": fdtd.PML, "periodic": fdtd.PeriodicBoundary, "object": fdtd.Object,
+            "absorbing": fdtd.AbsorbingObject, "anisotropic": fdtd.AnisotropicObject,
+            "point": fdtd.PointSource, "line": fdtd.LineSource, "plane": fdtd.PlaneSource,
+            "linedet": fdtd.LineDetector, "blockdet": fdtd.BlockDetector,
+            "currentdet": fdtd.CurrentDetector,
+        }[kind]
+        thing = cls(**kw)
+        grid[key] = thing
+        if kind == "anisotropic" and extra:
+            fill_offdiag(thing, extra)
+        made.append((kind, thing, kw, extra))
+    return grid, made
+
+
+def offdiag_values(shape5, extra):
+    rs = np.random.RandomState(extra["offdiag_seed"])
+    vals = extra["offdiag_scale"] * rs.randn(*shape5)
+    for c in range(3):
+        vals[..., c, c] = 0.0
+    return vals
+
+
+def fill_offdiag(obj, extra):
+    """Add reproducible off-diagonal entries to an anisotropic object's tensor."""
+    m = obj.inverse_permittivity
+    vals = offdiag_values(tuple(m.shape), extra)
+    if isinstance(m, np.ndarray):
+        m += vals
+    else:  # torch tensor of the engine under test
+        import torch
+
+        with torch.no_grad():
+            m += torch.as_tensor(vals, dtype=m.dtype, device=m.device)
+
+
+def run_scene(scene, grid):
+    """Advance ``grid`` as the scene prescribes."""
+    poke = scene.get("poke")
+    if poke is None:
+        grid.run(scene["steps"], progress_bar=False)
+        return
+    x, y, z, c = poke["cell"]
+    for _ in range(scene["steps"]):
+        grid.update_E()
+        grid.E[x, y, z, c] = poke_value(grid, poke)
+        grid.update_H()
+        grid.time_steps_passed += 1
+
+
+# ---------------------------------------------------------------------------
+# resolved (integer) description, used to build the oracle without the reference
+# ---------------------------------------------------------------------------
+def _ints(v):
+    return [int(i) for i in v]
+
+
+def resolve(scene, grid, made):
+    """Integer description of a grid built through the API (reference or engine)."""
+    out = dict(
+        grid=dict(
+            shape=[grid.Nx, grid.Ny, grid.Nz], grid_spacing=grid.grid_spacing,
+            courant_number=grid.courant_number,
+            permittivity=scene["grid"].get("permittivity", 1.0),
+            permeability=scene["grid"].get("permeability", 1.0),
+        ),
+        items=[], steps=scene["steps"], poke=scene.get("poke"),
+    )
+    arrays = {}
+    for n, (kind, t, kw, extra) in enumerate(made):
+        if kind == "pml":
+            cname = type(t).__name__  # _PMLXlow ...
+            axis = "XYZ".index(cname[4])
+            side = cname[5:]
+            out["items"].append(dict(kind=kind, axis=axis, side=side, thickness=int(t.thickness), a=t.a))
+        elif kind == "periodic":
+            out["items"].append(dict(kind=kind, axis="XYZ".index(type(t).__name__[-1])))
+        elif kind in ("object", "absorbing", "anisotropic"):
+            d = dict(kind=kind, box=_ints([t.x.start, t.x.stop, t.y.start, t.y.stop, t.z.start, t.z.stop]))
+            for field in ("permittivity", "conductivity"):
+                if field in kw:
+                    v = kw[field]
+                    if isinstance(v, np.ndarray):
+                        arrays[f"item{n}_{field}"] = v
+                        d[field] = f"@item{n}_{field}"
+                    else:
+                        d[field] = v
+            if extra:
+                d["extra"] = extra
+            out["items"].append(d)
+        elif kind == "point":
+            out["items"].append(dict(kind=kind, cell=_ints([t.x, t.y, t.z]), kw=kw_no_name(kw)))
+        elif kind == "line":
+            out["items"].append(dict(kind=kind, xs=_ints(t.x), ys=_ints(t.y), zs=_ints(t.z), kw=kw_no_name(kw)))
+        elif kind == "plane":
+            d = dict(kind=kind, box=_ints([t.x.start, t.x.stop, t.y.start, t.y.stop, t.z.start, t.z.stop]),
+                     kw=kw_no_name(kw), Epol=int(t._Epol), Hpol=int(t._Hpol))
+            out["items"].append(d)
+        elif kind in ("linedet", "blockdet", "currentdet"):
+            out["items"].append(dict(kind=kind, xs=_ints(t.x), ys=_ints(t.y), zs=_ints(t.z)))
+        else:
+            raise ValueError(kind)
+    return out, arrays
+
+
+def kw_no_name(kw):
+    return {k: v for k, v in kw.items() if k != "name"}
+
+
+def build_oracle(resolved, arrays):
+    """Build the numpy oracle from a resolved description."""
+    from oracle.yee_numpy import OracleGrid
+
+    g = resolved["grid"]
+    grid = OracleGrid(tuple(g["shape"]), grid_spacing=g["grid_spacing"],
+                      permittivity=g["permittivity"], permeability=g["permeability"])
+    assert grid.courant_number == g["courant_number"]
+    made = []
+
+    def val(v):
+        return arrays[v[1:]] if isinstance(v, str) and v.startswith("@") else v
+
+    for it in resolved["items"]:
+        k = it["kind"]
+        if k == "pml":
+            t = grid.add_pml(it["axis"], it["side"], it["thickness"], it["a"])
+        elif k == "periodic":
+            t = grid.add_periodic(it["axis"])
+        elif k in ("object", "absorbing", "anisotropic"):
+            t = grid.add_object(it["box"], val(it["permittivity"]), kind=k,
+                                conductivity=val(it.get("conductivity")))
+            if it.get("extra"):
+                fill_offdiag(t, it["extra"])
+        elif k == "point":
+            t = grid.add_point_source(it["cell"], **it["kw"])
+        elif k == "line":
+            t = grid.add_line_source(it["xs"], it["ys"], it["zs"], **it["kw"])
+        elif k == "plane":
+            t = grid.add_plane_source(it["box"], **it["kw"])
+            assert (t.Epol, t.Hpol) == (it["Epol"], it["Hpol"])
+        elif k == "linedet":
+            t = grid.add_line_detector(it["xs"], it["ys"], it["zs"])
+        elif k == "blockdet":
+            t = grid.add_block_detector(it["xs"], it["ys"], it["zs"])
+        elif k == "currentdet":
+            t = grid.add_current_detector(it["xs"], it["ys"], it["zs"])
+        else:
+            raise ValueError(k)
+        made.append((k, t))
+    return grid, made
+
+
+def run_oracle(resolved, grid):
+    poke = resolved.get("poke")
+    if poke is None:
+        grid.run(resolved["steps"])
+        return
+    x, y, z, c = poke["cell"]
+    for _ in range(resolved["steps"]):
+        grid.update_E()
+        grid.E[x, y, z, c] = poke_value(grid, poke)
+        grid.update_H()
+        grid.time_steps_passed += 1
+
+
+def dumps(resolved):
+    return json.dumps(resolved)
+
+
+def loads(s):
+    return json.loads(str(s))
