@@ -1,0 +1,232 @@
+"""Benchmark of the Yee time-stepping hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+Prints ONE JSON line (rank 0).  A "step" is one full Yee step (E half step + H
+half step) of the whole grid; `value` is cell-updates per second summed over all
+GPUs with the fields resident in HBM.
+
+Workloads (all synthetic, fields start at zero, a point source drives them):
+  m3v   512^3 float32, vacuum, PointSource            (default: the "512^3 float32
+        Yee update" the headline metric is quoted on)
+  m3    512^3 float32, 6 PML(10), anisotropic + absorbing objects, 3 LineDetectors
+  m2    256^3 float64, 6 PML(10), PointSource
+  c1    161x97x1 float64, the reference's README example
+With --gpus N > 1 the grid is N slabs of the single-GPU size along x (weak
+scaling), one process per GPU, halo planes exchanged over RCCL.
+
+Extra objects in the JSON line:
+  roofline      achieved algorithmic GB/s of the bulk kernels from HIP-event
+                timings taken inside the timed region, against the 8 TB/s HBM peak
+  cpu_baseline  the numpy oracle (a restatement of the reference's numpy backend)
+                timed on this machine's host cores on a bounded sample
+"""
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (spec)
+
+
+def build_workload(fdtd, name, n_slabs=1, rank=0):
+    """Returns (grid, cells_per_rank, bytes_per_cell_step, dtype label, description)."""
+    import numpy as np
+    import torch
+
+    if name in ("m3v", "m3"):
+        fdtd.set_backend("hip.float32")
+        shape, es, dt = (512, 512, 512), 4, "f32"
+    elif name == "m2":
+        fdtd.set_backend("hip.float64")
+        shape, es, dt = (256, 256, 256), 8, "f64"
+    elif name == "c1":
+        fdtd.set_backend("hip.float64")
+        shape, es, dt = (161, 97, 1), 8, "f64"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    if n_slabs > 1:
+        from fdtd_amd.parallel import SlabGrid
+
+        grid = SlabGrid((shape[0] * n_slabs, shape[1], shape[2]))
+    else:
+        grid = fdtd.Grid(shape)
+    nx, ny, nz = grid.Nx, grid.Ny, grid.Nz  # global extents
+    desc = f"{nx}x{ny}x{nz} {dt}"
+    if name == "m3v":
+        grid[nx // 2, ny // 2, nz // 2] = fdtd.PointSource(period=20)
+        desc += " vacuum + PointSource"
+    elif name == "m2":
+        for key in ((slice(0, 10),), (slice(-10, None),), (slice(None), slice(0, 10)),
+                    (slice(None), slice(-10, None)), (slice(None), slice(None), slice(0, 10)),
+                    (slice(None), slice(None), slice(-10, None))):
+            grid[key] = fdtd.PML()
+        grid[nx // 2, ny // 2, nz // 2] = fdtd.PointSource(period=20)
+        desc += " 6xPML(10) + PointSource"
+    elif name == "m3":
+        for key in ((slice(0, 10),), (slice(-10, None),), (slice(None), slice(0, 10)),
+                    (slice(None), slice(-10, None)), (slice(None), slice(None), slice(0, 10)),
+                    (slice(None), slice(None), slice(-10, None))):
+            grid[key] = fdtd.PML()
+        grid[nx // 2, ny // 2, nz // 2] = fdtd.PointSource(period=20)
+        ani = fdtd.AnisotropicObject(permittivity=2.5)
+        grid[128:192, 128:192, 128:192] = ani
+        off = 0.05 * np.random.RandomState(0).randn(64, 64, 64, 3, 3)
+        for c in range(3):
+            off[..., c, c] = 0
+        with torch.no_grad():
+            ani.inverse_permittivity += fdtd.backend.array(off)
+        grid[320:384, 128:192, 128:192] = fdtd.AbsorbingObject(permittivity=2.0, conductivity=1e-3)
+        grid[12:500, 256, 256] = fdtd.LineDetector()
+        grid[256, 12:500, 256] = fdtd.LineDetector()
+        grid[256, 256, 12:500] = fdtd.LineDetector()
+        desc += " 6xPML(10) + anisotropic 64^3 + absorbing 64^3 + 3 LineDetectors"
+    elif name == "c1":
+        S = slice
+        grid[11:32, 30:84, 0] = fdtd.Object(permittivity=1.7 ** 2)
+        grid[S(13e-6, 18e-6), S(5e-6, 8e-6), 0] = fdtd.Object(permittivity=1.5 ** 2)
+        grid[S(7.5e-6, 8.0e-6), S(11.8e-6, 13.0e-6), 0] = fdtd.LineSource(period=1550e-9 / 3e8)
+        grid[12e-6, :, 0] = fdtd.LineDetector()
+        grid[0:10, :, :] = fdtd.PML()
+        grid[-10:, :, :] = fdtd.PML()
+        grid[:, 0:10, :] = fdtd.PML()
+        grid[:, -10:, :] = fdtd.PML()
+        desc += " README example"
+    cells = shape[0] * shape[1] * shape[2]
+    # bulk traffic per cell and step: each half step reads 9 values, writes 3
+    return grid, cells, 24 * es, dt, desc
+
+
+def cpu_baseline(name, budget_s=15.0):
+    """The numpy oracle on a bounded sample of the same scene (rank 0, N=1 only)."""
+    from oracle.yee_numpy import OracleGrid  # CPU baseline leg: allowed use of the oracle
+
+    if name == "c1":
+        n, shape = 1, (161, 97, 1)
+    else:
+        n, shape = 128, (128, 128, 128)
+    g = OracleGrid(shape)
+    if name in ("m2", "m3"):
+        for axis in range(3):
+            g.add_pml(axis, "low", 10)
+            g.add_pml(axis, "high", 10)
+    if name == "c1":
+        for axis in range(2):
+            g.add_pml(axis, "low", 10)
+            g.add_pml(axis, "high", 10)
+        g.add_object((11, 32, 30, 84, 0, 1), 1.7 ** 2)
+    g.add_point_source((shape[0] // 2, shape[1] // 2, shape[2] // 2), period=20)
+    g.step()  # warm-up
+    t0, steps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s and steps < 2000:
+        g.step()
+        steps += 1
+    dt = time.perf_counter() - t0
+    cells = shape[0] * shape[1] * shape[2]
+    return dict(
+        value=cells * steps / dt / 1e9, unit="Gcells/s", cores=1, kind="port",
+        sample=f"numpy float64 oracle, {shape[0]}x{shape[1]}x{shape[2]} cells, same boundaries and "
+               f"source, {steps} steps in {dt:.1f} s (numpy elementwise ops use one core; "
+               f"host has {os.cpu_count()} logical CPUs)",
+    )
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="m3v")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import fdtd_amd as fdtd
+    from fdtd_amd import _lib
+
+    grid, cells, bytes_per_cell, dt, desc = build_workload(fdtd, args.workload, world, rank)
+    lib = _lib.load()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    grid.run(args.warmup, progress_bar=False)
+    sync()
+    plan = grid._plan
+    _lib.check(lib.fdtdhip_plan_enable_timing(plan, 1))
+    sync()
+    t0 = time.perf_counter()
+    grid.run(args.steps, progress_bar=False)
+    sync()
+    elapsed = time.perf_counter() - t0
+    msE, nE, msH, nH = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
+    _lib.check(lib.fdtdhip_plan_get_timing(plan, ctypes.byref(msE), ctypes.byref(nE),
+                                            ctypes.byref(msH), ctypes.byref(nH)))
+    _lib.check(lib.fdtdhip_plan_enable_timing(plan, 0))
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_cells = cells * world
+        value = total_cells * args.steps / elapsed / 1e9
+        # dominant kernel: the bulk half-step kernel (E and H variants move the same bytes)
+        launches = nE.value + nH.value
+        avg_ms = (msE.value + msH.value) / max(launches, 1)
+        bytes_per_launch = cells * bytes_per_cell / 2
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            rec = json.load(open(pmc)).get(args.workload)
+            if rec:
+                traffic = rec.get("bytes_per_launch")
+        out = {
+            "metric": "Yee cell-updates/s", "value": round(value, 3), "unit": "Gcells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
+            "config": {"workload": desc, "name": args.workload,
+                       "parallelism": f"x-slab x{world}" if world > 1 else "single GPU",
+                       "cells_per_gpu": cells},
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "kernel": "bulk half-step kernel (E and H)",
+                "bytes_per_launch": bytes_per_launch,
+                "avg_launch_ms": round(avg_ms, 4),
+                "avg_launch_ms_E": round(msE.value / max(nE.value, 1), 4),
+                "avg_launch_ms_H": round(msH.value / max(nH.value, 1), 4),
+                "launches": launches,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

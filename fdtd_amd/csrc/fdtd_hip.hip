@@ -1,0 +1,654 @@
+// libfdtd_hip: C ABI (include/fdtd_hip.h) over the HIP kernels of this directory.
+//
+// Host side of a plan: keeps the borrowed field pointers, the ordered boundary
+// list, the object / source / detector tables, and turns one half step of the
+// reference's Grid (reference fdtd/grid.py:275-325) into a short, fixed
+// sequence of kernel launches on the plan's stream.
+#include "../../include/fdtd_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "plan.hpp"
+#include "yee_generic.hpp"
+#include "yee_tiled.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      return fail(-2, std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+      switched = hipSetDevice(dev) == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+struct PmlH {
+  int axis, side, t, lo;
+  void* psiE;
+  void* psiH;
+  void *bE, *cE, *bH, *cH;  // device arrays of the plan's element type
+  bool fused;               // no periodic boundary precedes it in the list
+};
+
+struct BoundaryRef {
+  int kind;  // 0 = pml (index into pmls), 1 = periodic (axis)
+  int idx;
+};
+
+struct ObjH {
+  int kind;
+  int box[6];
+  const void* inv;
+  const void* absorb;
+};
+
+struct SourceH {
+  int kind, compE, compH;
+  int64_t n;
+  int box[6];
+  int64_t* elem = nullptr;    // device: flat element index of (cell, compE)
+  double* profile = nullptr;  // device
+  double amplitude = 0;       // SET_BOX
+  int serial = 0;
+  double period, phase, frequency, hanning_dt, cycle;
+  int pulse;
+};
+
+struct DetH {
+  int kind;
+  int64_t n;
+  int64_t* cell = nullptr;  // device flat cell index (CELLS)
+  int32_t* xyz = nullptr;   // device (CURRENT)
+  double spacing;
+  char* outE = nullptr;
+  char* outH = nullptr;
+  int64_t capacity = 0, usedE = 0, usedH = 0;
+};
+
+}  // namespace
+
+struct fdtdhip_plan {
+  int nx, ny, nz, dtype, device;
+  double sc;
+  hipStream_t stream = nullptr;
+  void *E = nullptr, *H = nullptr;
+  const void *inv_eps = nullptr, *inv_mu = nullptr;
+  const void *H_below = nullptr, *E_above = nullptr;
+  std::vector<BoundaryRef> boundaries;
+  std::vector<PmlH> pmls;
+  std::vector<ObjH> objs;
+  std::vector<SourceH> sources;
+  std::vector<DetH> dets;
+  void* obj_table = nullptr;  // device ObjK<T>[]
+  bool obj_dirty = false;
+  std::vector<void*> owned;   // device allocations released by reset/destroy
+  // optional kernel timing (fdtdhip_plan_enable_timing)
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  std::vector<int> ev_phase;  // phase (1 = E) of each used pair
+  double ms[2] = {0, 0};
+  int64_t launches[2] = {0, 0};
+  size_t esize() const { return dtype == FDTDHIP_F32 ? 4 : 8; }
+  int64_t cells() const { return (int64_t)nx * ny * nz; }
+};
+
+namespace {
+
+using namespace fdtdhip;
+
+inline unsigned blocks_for(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+int release_tables(fdtdhip_plan* p) {
+  for (void* d : p->owned) (void)hipFree(d);
+  p->owned.clear();
+  if (p->obj_table) (void)hipFree(p->obj_table);
+  p->obj_table = nullptr;
+  p->boundaries.clear();
+  p->pmls.clear();
+  p->objs.clear();
+  p->sources.clear();
+  p->dets.clear();
+  p->obj_dirty = false;
+  return 0;
+}
+
+template <typename T>
+int upload_profile(fdtdhip_plan* p, const double* host, int n, void** out) {
+  std::vector<T> tmp(n);
+  for (int i = 0; i < n; ++i) tmp[i] = (T)host[i];
+  void* d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(T) * (size_t)n));
+  p->owned.push_back(d);
+  HIPCHK(hipMemcpy(d, tmp.data(), sizeof(T) * (size_t)n, hipMemcpyHostToDevice));
+  *out = d;
+  return 0;
+}
+
+template <typename T>
+int sync_obj_table(fdtdhip_plan* p) {
+  if (!p->obj_dirty) return 0;
+  if (p->obj_table) {
+    // the table may still be read by kernels in flight on the plan's stream
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipFree(p->obj_table));
+    p->obj_table = nullptr;
+  }
+  std::vector<ObjK<T>> tab(p->objs.size());
+  for (size_t o = 0; o < p->objs.size(); ++o) {
+    const ObjH& h = p->objs[o];
+    tab[o].inv = (const T*)h.inv;
+    tab[o].absorb = (const T*)h.absorb;
+    tab[o].kind = h.kind;
+    tab[o].x0 = h.box[0]; tab[o].x1 = h.box[1];
+    tab[o].y0 = h.box[2]; tab[o].y1 = h.box[3];
+    tab[o].z0 = h.box[4]; tab[o].z1 = h.box[5];
+  }
+  if (!tab.empty()) {
+    HIPCHK(hipMalloc(&p->obj_table, sizeof(ObjK<T>) * tab.size()));
+    HIPCHK(hipMemcpy(p->obj_table, tab.data(), sizeof(ObjK<T>) * tab.size(),
+                     hipMemcpyHostToDevice));
+  }
+  p->obj_dirty = false;
+  return 0;
+}
+
+template <typename T>
+PmlK<T> make_pmlk(const fdtdhip_plan* p, const PmlH& h, bool phaseE) {
+  PmlK<T> k;
+  k.psi = (T*)(phaseE ? h.psiE : h.psiH);
+  k.b = (const T*)(phaseE ? h.bE : h.bH);
+  k.c = (const T*)(phaseE ? h.cE : h.cH);
+  k.axis = h.axis;
+  k.lo = h.lo;
+  k.t = h.t;
+  k.fused = h.fused ? 1 : 0;
+  k.sy = h.axis == 1 ? h.t : p->ny;
+  k.sz = h.axis == 2 ? h.t : p->nz;
+  return k;
+}
+
+int drain_timing(fdtdhip_plan* p) {
+  for (size_t i = 0; i < p->ev_phase.size(); ++i) {
+    float ms = 0;
+    HIPCHK(hipEventSynchronize(p->ev_pool[i].second));
+    HIPCHK(hipEventElapsedTime(&ms, p->ev_pool[i].first, p->ev_pool[i].second));
+    p->ms[p->ev_phase[i]] += ms;
+    p->launches[p->ev_phase[i]] += 1;
+  }
+  p->ev_phase.clear();
+  return 0;
+}
+
+template <typename T>
+int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1);
+
+template <typename T>
+int bulk(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
+  if (!p->timing || x0 == x1) return bulk_launch<T>(p, phaseE, x0, x1);
+  if (p->ev_phase.size() >= 2048)
+    if (int rc = drain_timing(p)) return rc;
+  const size_t slot = p->ev_phase.size();
+  if (slot >= p->ev_pool.size()) {
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    p->ev_pool.push_back({a, b});
+  }
+  HIPCHK(hipEventRecord(p->ev_pool[slot].first, p->stream));
+  const int rc = bulk_launch<T>(p, phaseE, x0, x1);
+  HIPCHK(hipEventRecord(p->ev_pool[slot].second, p->stream));
+  p->ev_phase.push_back(phaseE ? 1 : 0);
+  return rc;
+}
+
+template <typename T>
+int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
+  if (!p->E || !p->H || !p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
+  if (x0 < 0 || x1 > p->nx || x0 > x1) return fail(-1, "bad x range");
+  if (x0 == x1) return 0;
+  if (int rc = sync_obj_table<T>(p)) return rc;
+  BulkArgs<T> a;
+  a.F = (T*)(phaseE ? p->E : p->H);
+  a.G = (const T*)(phaseE ? p->H : p->E);
+  a.mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
+  a.ghost = (const T*)(phaseE ? p->H_below : p->E_above);
+  a.nx = p->nx; a.ny = p->ny; a.nz = p->nz;
+  a.x0 = x0; a.x1 = x1;
+  a.sc = (T)p->sc;
+  a.npml = (int)p->pmls.size();
+  a.nobj = phaseE ? (int)p->objs.size() : 0;
+  a.obj = (const ObjK<T>*)p->obj_table;
+  for (int i = 0; i < a.npml; ++i) a.pml[i] = make_pmlk<T>(p, p->pmls[i], phaseE);
+
+  if (tiled_applicable<T>(a)) return launch_tiled<T>(a, phaseE, p->stream) ? fail(-2, "tiled launch failed") : 0;
+
+  const int64_t ncell = (int64_t)(x1 - x0) * p->ny * p->nz;
+  const dim3 grid(blocks_for(ncell)), block(256);
+  const bool pml = a.npml > 0, obj = a.nobj > 0;
+  if (phaseE) {
+    if (pml && obj) hipLaunchKernelGGL((bulk_E_generic<T, true, true>), grid, block, 0, p->stream, a);
+    else if (pml) hipLaunchKernelGGL((bulk_E_generic<T, true, false>), grid, block, 0, p->stream, a);
+    else if (obj) hipLaunchKernelGGL((bulk_E_generic<T, false, true>), grid, block, 0, p->stream, a);
+    else hipLaunchKernelGGL((bulk_E_generic<T, false, false>), grid, block, 0, p->stream, a);
+  } else {
+    if (pml) hipLaunchKernelGGL((bulk_H_generic<T, true>), grid, block, 0, p->stream, a);
+    else hipLaunchKernelGGL((bulk_H_generic<T, false>), grid, block, 0, p->stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+double waveform(const SourceH& s, int64_t q) {
+  // reference fdtd/sources.py:99-110 and fdtd/waveforms.py:8-9, same operation order
+  if (s.pulse) {
+    const int64_t t1 = (int64_t)(2 * M_PI / (s.frequency * s.hanning_dt / s.cycle));
+    if (q < t1) {
+      const double f = s.frequency, t = (double)q * s.hanning_dt, n = s.cycle;
+      return (1.0 / 2.0) * (1 - std::cos(f * t / n)) * (std::sin(f * t));
+    }
+    return 0.0;
+  }
+  return std::sin(2 * M_PI * (double)q / s.period + s.phase);
+}
+
+template <typename T>
+int post(fdtdhip_plan* p, bool phaseE, int64_t q) {
+  T* F = (T*)(phaseE ? p->E : p->H);
+  const T* mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
+  if (!F || !mat) return fail(-1, "fields not set");
+  // boundaries that follow the first periodic one, in list order
+  bool seen_periodic = false;
+  for (const BoundaryRef& b : p->boundaries) {
+    if (b.kind == 1) {
+      seen_periodic = true;
+      const int axis = b.idx;
+      const int n = axis == 0 ? p->nx : (axis == 1 ? p->ny : p->nz);
+      if (n < 2) continue;  // copy of a plane onto itself
+      const int64_t total = p->cells() / n * 3;
+      const int dst = phaseE ? 0 : n - 1, src = phaseE ? n - 1 : 0;
+      hipLaunchKernelGGL((periodic_copy<T>), dim3(blocks_for(total)), dim3(256), 0, p->stream, F,
+                         p->nx, p->ny, p->nz, axis, dst, src);
+    } else if (seen_periodic) {
+      const PmlH& h = p->pmls[b.idx];
+      PmlK<T> k = make_pmlk<T>(p, h, phaseE);
+      const int64_t slab = (int64_t)(h.axis == 0 ? h.t : p->nx) * k.sy * k.sz;
+      hipLaunchKernelGGL((pml_apply_slab<T>), dim3(blocks_for(slab)), dim3(256), 0, p->stream, F,
+                         mat, k, p->nx, p->ny, p->nz, (T)p->sc, phaseE ? T(1) : T(-1));
+    }
+  }
+  for (const SourceH& s : p->sources) {
+    const double w = waveform(s, q);
+    if (s.kind == FDTDHIP_SRC_ADD_POINTS) {
+      if (!phaseE) continue;
+      hipLaunchKernelGGL((source_add_points<T>), dim3(s.serial ? 1 : blocks_for(s.n, 64)),
+                         dim3(64), 0, p->stream, F, s.elem, s.profile, w, s.n, s.serial);
+    } else {
+      const int64_t total =
+          (int64_t)(s.box[1] - s.box[0]) * (s.box[3] - s.box[2]) * (s.box[5] - s.box[4]);
+      if (total <= 0) continue;
+      hipLaunchKernelGGL((source_set_box<T>), dim3(blocks_for(total)), dim3(256), 0, p->stream, F,
+                         p->ny, p->nz, s.box[0], s.box[1], s.box[2], s.box[3], s.box[4], s.box[5],
+                         phaseE ? s.compE : s.compH, (T)(s.amplitude * w));
+    }
+  }
+  for (DetH& d : p->dets) {
+    if (d.kind == FDTDHIP_DET_CELLS) {
+      int64_t& used = phaseE ? d.usedE : d.usedH;
+      char* base = phaseE ? d.outE : d.outH;
+      if (d.n == 0) { ++used; continue; }
+      if (!base || used >= d.capacity) return fail(-3, "detector output capacity exhausted");
+      T* out = (T*)base + used * d.n * 3;
+      hipLaunchKernelGGL((detect_cells<T>), dim3(blocks_for(d.n * 3)), dim3(256), 0, p->stream, F,
+                         d.cell, out, d.n);
+      ++used;
+    } else if (!phaseE) {
+      if (d.n == 0) { ++d.usedH; continue; }
+      if (!d.outH || d.usedH >= d.capacity) return fail(-3, "detector output capacity exhausted");
+      T* out = (T*)d.outH + d.usedH * d.n;
+      hipLaunchKernelGGL((detect_current<T>), dim3(blocks_for(d.n, 64)), dim3(64), 0, p->stream,
+                         (const T*)p->H, d.xyz, out, d.n, p->nx, p->ny, p->nz, (T)d.spacing);
+      ++d.usedH;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int curl_launch(const void* in, void* out, int nx, int ny, int nz, bool forward, void* stream) {
+  const int64_t n = (int64_t)nx * ny * nz;
+  if (n == 0) return 0;
+  if (forward)
+    hipLaunchKernelGGL((curl_only<T, true>), dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)in, (T*)out, nx, ny, nz);
+  else
+    hipLaunchKernelGGL((curl_only<T, false>), dim3(blocks_for(n)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)in, (T*)out, nx, ny, nz);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+#define DISPATCH(p, call_f32, call_f64) ((p)->dtype == FDTDHIP_F32 ? (call_f32) : (call_f64))
+
+}  // namespace
+
+extern "C" {
+
+int fdtdhip_abi_version(void) { return FDTDHIP_ABI_VERSION; }
+
+const char* fdtdhip_last_error(void) { return g_err.c_str(); }
+
+int fdtdhip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int fdtdhip_plan_create(fdtdhip_plan** out, int nx, int ny, int nz, int dtype, double courant,
+                        int device) {
+  if (!out) return fail(-1, "null output pointer");
+  if (nx < 1 || ny < 1 || nz < 1) return fail(-1, "grid extents must be >= 1");
+  if (dtype != FDTDHIP_F32 && dtype != FDTDHIP_F64) return fail(-1, "unknown dtype");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    return fail(-4, "no HIP device available: the hip backend needs an AMD GPU");
+  if (device < 0 || device >= n) return fail(-1, "device ordinal out of range");
+  fdtdhip_plan* p = new fdtdhip_plan();
+  p->nx = nx; p->ny = ny; p->nz = nz; p->dtype = dtype; p->device = device; p->sc = courant;
+  *out = p;
+  return 0;
+}
+
+int fdtdhip_plan_reset(fdtdhip_plan* p) {
+  if (!p) return fail(-1, "null plan");
+  DeviceGuard g(p->device);
+  (void)hipStreamSynchronize(p->stream);
+  return release_tables(p);
+}
+
+int fdtdhip_plan_destroy(fdtdhip_plan* p) {
+  if (!p) return 0;
+  {
+    DeviceGuard g(p->device);
+    (void)hipStreamSynchronize(p->stream);
+    release_tables(p);
+    for (auto& e : p->ev_pool) {
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
+  }
+  delete p;
+  return 0;
+}
+
+int fdtdhip_plan_set_stream(fdtdhip_plan* p, void* stream) {
+  if (!p) return fail(-1, "null plan");
+  p->stream = (hipStream_t)stream;
+  return 0;
+}
+
+int fdtdhip_plan_set_fields(fdtdhip_plan* p, void* E, void* H, const void* inv_eps,
+                            const void* inv_mu) {
+  if (!p) return fail(-1, "null plan");
+  if (!E || !H || !inv_eps || !inv_mu) return fail(-1, "null field pointer");
+  p->E = E; p->H = H; p->inv_eps = inv_eps; p->inv_mu = inv_mu;
+  return 0;
+}
+
+int fdtdhip_plan_set_halo(fdtdhip_plan* p, const void* H_below, const void* E_above) {
+  if (!p) return fail(-1, "null plan");
+  p->H_below = H_below;
+  p->E_above = E_above;
+  return 0;
+}
+
+int fdtdhip_plan_add_pml(fdtdhip_plan* p, int axis, int side, int t, const double* bE,
+                         const double* cE, const double* bH, const double* cH, void* psiE,
+                         void* psiH) {
+  if (!p) return fail(-1, "null plan");
+  if (axis < 0 || axis > 2 || (side != 0 && side != 1)) return fail(-1, "bad PML placement");
+  const int n = axis == 0 ? p->nx : (axis == 1 ? p->ny : p->nz);
+  if (t < 1 || t > n) return fail(-1, "PML thickness out of range");
+  if (!bE || !cE || !bH || !cH || !psiE || !psiH) return fail(-1, "null PML array");
+  if ((int)p->pmls.size() >= fdtdhip::MAX_PML) return fail(-1, "too many PMLs (one per face)");
+  DeviceGuard g(p->device);
+  PmlH h;
+  h.axis = axis; h.side = side; h.t = t; h.lo = side == 0 ? 0 : n - t;
+  h.psiE = psiE; h.psiH = psiH;
+  h.fused = true;
+  for (const BoundaryRef& b : p->boundaries)
+    if (b.kind == 1) h.fused = false;
+  int rc;
+  if (p->dtype == FDTDHIP_F32) {
+    if ((rc = upload_profile<float>(p, bE, t, &h.bE)) || (rc = upload_profile<float>(p, cE, t, &h.cE)) ||
+        (rc = upload_profile<float>(p, bH, t, &h.bH)) || (rc = upload_profile<float>(p, cH, t, &h.cH)))
+      return rc;
+  } else {
+    if ((rc = upload_profile<double>(p, bE, t, &h.bE)) || (rc = upload_profile<double>(p, cE, t, &h.cE)) ||
+        (rc = upload_profile<double>(p, bH, t, &h.bH)) || (rc = upload_profile<double>(p, cH, t, &h.cH)))
+      return rc;
+  }
+  p->pmls.push_back(h);
+  p->boundaries.push_back({0, (int)p->pmls.size() - 1});
+  return 0;
+}
+
+int fdtdhip_plan_add_periodic(fdtdhip_plan* p, int axis) {
+  if (!p) return fail(-1, "null plan");
+  if (axis < 0 || axis > 2) return fail(-1, "bad axis");
+  p->boundaries.push_back({1, axis});
+  return 0;
+}
+
+int fdtdhip_plan_add_object(fdtdhip_plan* p, int kind, const int32_t box[6], const void* inv,
+                            const void* absorb) {
+  if (!p) return fail(-1, "null plan");
+  if (kind < 0 || kind > 2) return fail(-1, "unknown object kind");
+  if (!box || !inv) return fail(-1, "null object array");
+  if (kind == FDTDHIP_OBJ_ABSORBING && !absorb) return fail(-1, "absorbing object needs its factor");
+  const int lim[3] = {p->nx, p->ny, p->nz};
+  for (int d = 0; d < 3; ++d)
+    if (box[2 * d] < 0 || box[2 * d + 1] > lim[d] || box[2 * d] > box[2 * d + 1])
+      return fail(-1, "object box outside the grid");
+  ObjH h;
+  h.kind = kind;
+  for (int i = 0; i < 6; ++i) h.box[i] = box[i];
+  h.inv = inv;
+  h.absorb = absorb;
+  p->objs.push_back(h);
+  p->obj_dirty = true;
+  return 0;
+}
+
+int fdtdhip_plan_add_source(fdtdhip_plan* p, int kind, int compE, int compH, int64_t n,
+                            const int32_t* cells, const double* profile, double period,
+                            double phase, int pulse, double frequency, double hanning_dt,
+                            double cycle) {
+  if (!p) return fail(-1, "null plan");
+  if (!cells || !profile) return fail(-1, "null source array");
+  if (compE < 0 || compE > 2 || compH < 0 || compH > 2) return fail(-1, "bad component");
+  DeviceGuard g(p->device);
+  SourceH s;
+  s.kind = kind; s.compE = compE; s.compH = compH; s.n = n;
+  s.period = period; s.phase = phase; s.pulse = pulse; s.frequency = frequency;
+  s.hanning_dt = hanning_dt; s.cycle = cycle;
+  const int lim[3] = {p->nx, p->ny, p->nz};
+  if (kind == FDTDHIP_SRC_SET_BOX) {
+    for (int d = 0; d < 3; ++d)
+      if (cells[2 * d] < 0 || cells[2 * d + 1] > lim[d] || cells[2 * d] > cells[2 * d + 1])
+        return fail(-1, "source box outside the grid");
+    for (int i = 0; i < 6; ++i) s.box[i] = cells[i];
+    s.amplitude = profile[0];
+  } else if (kind == FDTDHIP_SRC_ADD_POINTS) {
+    if (n < 0) return fail(-1, "negative point count");
+    std::vector<int64_t> elem((size_t)n);
+    std::set<int64_t> seen;
+    for (int64_t i = 0; i < n; ++i) {
+      for (int d = 0; d < 3; ++d)
+        if (cells[3 * i + d] < 0 || cells[3 * i + d] >= lim[d])
+          return fail(-1, "source point outside the grid");
+      elem[i] = ((((int64_t)cells[3 * i] * p->ny) + cells[3 * i + 1]) * p->nz + cells[3 * i + 2]) * 3 + compE;
+      if (!seen.insert(elem[i]).second) s.serial = 1;
+    }
+    if (n > 0) {
+      HIPCHK(hipMalloc((void**)&s.elem, sizeof(int64_t) * (size_t)n));
+      p->owned.push_back(s.elem);
+      HIPCHK(hipMalloc((void**)&s.profile, sizeof(double) * (size_t)n));
+      p->owned.push_back(s.profile);
+      HIPCHK(hipMemcpy(s.elem, elem.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(s.profile, profile, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    }
+  } else {
+    return fail(-1, "unknown source kind");
+  }
+  p->sources.push_back(s);
+  return 0;
+}
+
+int fdtdhip_plan_add_detector(fdtdhip_plan* p, int kind, int64_t n, const int32_t* cells,
+                              double spacing) {
+  if (!p) return fail(-1, "null plan");
+  if (n < 0 || (n > 0 && !cells)) return fail(-1, "bad detector point list");
+  DeviceGuard g(p->device);
+  DetH d;
+  d.kind = kind; d.n = n; d.spacing = spacing;
+  const int lim[3] = {p->nx, p->ny, p->nz};
+  for (int64_t i = 0; i < n; ++i)
+    for (int c = 0; c < 3; ++c)
+      if (cells[3 * i + c] < 0 || cells[3 * i + c] >= lim[c])
+        return fail(-1, "detector point outside the grid");
+  if (kind == FDTDHIP_DET_CELLS) {
+    std::vector<int64_t> cell((size_t)n);
+    for (int64_t i = 0; i < n; ++i)
+      cell[i] = (((int64_t)cells[3 * i] * p->ny) + cells[3 * i + 1]) * p->nz + cells[3 * i + 2];
+    if (n > 0) {
+      HIPCHK(hipMalloc((void**)&d.cell, sizeof(int64_t) * (size_t)n));
+      p->owned.push_back(d.cell);
+      HIPCHK(hipMemcpy(d.cell, cell.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice));
+    }
+  } else if (kind == FDTDHIP_DET_CURRENT) {
+    if (n > 0) {
+      HIPCHK(hipMalloc((void**)&d.xyz, sizeof(int32_t) * 3 * (size_t)n));
+      p->owned.push_back(d.xyz);
+      HIPCHK(hipMemcpy(d.xyz, cells, sizeof(int32_t) * 3 * (size_t)n, hipMemcpyHostToDevice));
+    }
+  } else {
+    return fail(-1, "unknown detector kind");
+  }
+  p->dets.push_back(d);
+  return (int)p->dets.size() - 1;
+}
+
+int fdtdhip_plan_set_detector_output(fdtdhip_plan* p, int id, void* outE, void* outH,
+                                     int64_t capacity) {
+  if (!p) return fail(-1, "null plan");
+  if (id < 0 || id >= (int)p->dets.size()) return fail(-1, "unknown detector id");
+  DetH& d = p->dets[id];
+  d.outE = (char*)outE; d.outH = (char*)outH;
+  d.capacity = capacity;
+  d.usedE = d.usedH = 0;
+  return 0;
+}
+
+int fdtdhip_update_E_bulk(fdtdhip_plan* p, int x0, int x1) {
+  if (!p) return fail(-1, "null plan");
+  DeviceGuard g(p->device);
+  return DISPATCH(p, bulk<float>(p, true, x0, x1), bulk<double>(p, true, x0, x1));
+}
+int fdtdhip_update_H_bulk(fdtdhip_plan* p, int x0, int x1) {
+  if (!p) return fail(-1, "null plan");
+  DeviceGuard g(p->device);
+  return DISPATCH(p, bulk<float>(p, false, x0, x1), bulk<double>(p, false, x0, x1));
+}
+int fdtdhip_update_E_post(fdtdhip_plan* p, int64_t q) {
+  if (!p) return fail(-1, "null plan");
+  DeviceGuard g(p->device);
+  return DISPATCH(p, post<float>(p, true, q), post<double>(p, true, q));
+}
+int fdtdhip_update_H_post(fdtdhip_plan* p, int64_t q) {
+  if (!p) return fail(-1, "null plan");
+  DeviceGuard g(p->device);
+  return DISPATCH(p, post<float>(p, false, q), post<double>(p, false, q));
+}
+
+int fdtdhip_update_E(fdtdhip_plan* p, int64_t q) {
+  if (!p) return fail(-1, "null plan");
+  if (int rc = fdtdhip_update_E_bulk(p, 0, p->nx)) return rc;
+  return fdtdhip_update_E_post(p, q);
+}
+int fdtdhip_update_H(fdtdhip_plan* p, int64_t q) {
+  if (!p) return fail(-1, "null plan");
+  if (int rc = fdtdhip_update_H_bulk(p, 0, p->nx)) return rc;
+  return fdtdhip_update_H_post(p, q);
+}
+
+int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
+  if (!p) return fail(-1, "null plan");
+  for (int64_t s = 0; s < nsteps; ++s) {
+    if (int rc = fdtdhip_update_E(p, q0 + s)) return rc;
+    if (int rc = fdtdhip_update_H(p, q0 + s)) return rc;
+  }
+  return 0;
+}
+
+int fdtdhip_plan_enable_timing(fdtdhip_plan* p, int on) {
+  if (!p) return fail(-1, "null plan");
+  DeviceGuard g(p->device);
+  if (int rc = drain_timing(p)) return rc;
+  p->timing = on != 0;
+  p->ms[0] = p->ms[1] = 0;
+  p->launches[0] = p->launches[1] = 0;
+  return 0;
+}
+
+int fdtdhip_plan_get_timing(fdtdhip_plan* p, double* ms_E, int64_t* launches_E, double* ms_H,
+                            int64_t* launches_H) {
+  if (!p) return fail(-1, "null plan");
+  DeviceGuard g(p->device);
+  if (int rc = drain_timing(p)) return rc;
+  if (ms_E) *ms_E = p->ms[1];
+  if (launches_E) *launches_E = p->launches[1];
+  if (ms_H) *ms_H = p->ms[0];
+  if (launches_H) *launches_H = p->launches[0];
+  p->ms[0] = p->ms[1] = 0;
+  p->launches[0] = p->launches[1] = 0;
+  return 0;
+}
+
+int fdtdhip_curl_E(const void* E, void* out, int nx, int ny, int nz, int dtype, void* stream) {
+  if (!E || !out) return fail(-1, "null pointer");
+  return dtype == FDTDHIP_F32 ? curl_launch<float>(E, out, nx, ny, nz, true, stream)
+                              : curl_launch<double>(E, out, nx, ny, nz, true, stream);
+}
+int fdtdhip_curl_H(const void* H, void* out, int nx, int ny, int nz, int dtype, void* stream) {
+  if (!H || !out) return fail(-1, "null pointer");
+  return dtype == FDTDHIP_F32 ? curl_launch<float>(H, out, nx, ny, nz, false, stream)
+                              : curl_launch<double>(H, out, nx, ny, nz, false, stream);
+}
+
+}  // extern "C"

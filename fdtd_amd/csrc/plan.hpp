@@ -1,0 +1,57 @@
+// Plan data structures shared by the kernels and the C ABI of libfdtd_hip.
+//
+// Field layout everywhere: C-contiguous (nx, ny, nz, 3) -- cell major, the three
+// vector components of one cell adjacent -- exactly the arrays the reference
+// keeps on its Grid (reference fdtd/grid.py:135-151).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fdtdhip {
+
+constexpr int MAX_PML = 6;  // one per face: the reference refuses a second boundary on a face
+                            // (reference fdtd/boundaries.py:296-343)
+
+// One PML face as the kernels see it, for one half step (E or H).
+template <typename T>
+struct PmlK {
+  T* psi;       // (2, slab cells): [0] -> component u=(axis+1)%3, [1] -> component v=(axis+2)%3
+  const T* b;   // (t) decay of the memory variable along the normal axis
+  const T* c;   // (t) gain of the field difference along the normal axis
+  int axis;     // normal axis
+  int lo;       // first grid index of the slab along `axis`
+  int t;        // thickness
+  int fused;    // 1: the field correction is applied inside the bulk kernel;
+                // 0: a periodic boundary precedes this PML in the boundary list, so the
+                //    correction is applied by a later slab kernel
+  int sy, sz;   // slab extents along y and z (x extent not needed for indexing)
+};
+
+// One object box (reference fdtd/objects.py).
+template <typename T>
+struct ObjK {
+  const T* inv;     // (box,3) or (box,3,3)
+  const T* absorb;  // (box,3) or null
+  int kind;
+  int x0, x1, y0, y1, z0, z1;
+};
+
+// Arguments of the fused bulk kernels.  `F` is the field being advanced, `G` the
+// field whose curl drives it, `mat` the matching inverse material array.
+template <typename T>
+struct BulkArgs {
+  T* F;
+  const T* G;
+  const T* mat;
+  const T* ghost;  // neighbour slab's plane of G (ny,nz,3) or null at a true domain edge
+  int nx, ny, nz;
+  int x0, x1;      // planes to process
+  T sc;            // Courant number
+  int npml;
+  int nobj;
+  const ObjK<T>* obj;
+  PmlK<T> pml[MAX_PML];
+};
+
+}  // namespace fdtdhip

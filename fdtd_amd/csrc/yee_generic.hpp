@@ -1,0 +1,320 @@
+// Shape-agnostic Yee half-step kernels: one lane per cell, lanes running along
+// the flattened (y, z) index so that a wavefront reads 64 adjacent cells
+// (64 x 3 components, contiguous).  These kernels carry every feature of the
+// half step and are used for any grid shape (2-D grids with nz == 1, thin
+// slabs, ragged sizes).  Neighbour values are re-read through L1/L2.
+//
+// Arithmetic follows the reference expression by expression, in its order, and
+// the library is built with -ffp-contract=off, so float64 results equal the
+// reference's numpy results (see the citations at each block).
+#pragma once
+
+#include "plan.hpp"
+
+namespace fdtdhip {
+
+template <typename T>
+__device__ __forceinline__ void pml_pick(int axis, T d_x_y, T d_x_z, T d_y_x, T d_y_z, T d_z_x,
+                                         T d_z_y, T& dFu, T& dFv) {
+  // d_a_w = difference of component w along axis a.  u=(axis+1)%3, v=(axis+2)%3.
+  if (axis == 0) { dFu = d_x_y; dFv = d_x_z; }
+  else if (axis == 1) { dFu = d_y_z; dFv = d_y_x; }
+  else { dFu = d_z_x; dFv = d_z_y; }
+}
+
+// ---------------------------------------------------------------------------
+// E half step: PML memory update (reference fdtd/boundaries.py:422-448),
+// curl_H (fdtd/grid.py:54-76), E += sc*inv_eps*curl (grid.py:283), objects
+// (fdtd/objects.py:116-126, 204-218, 251-266), PML correction (boundaries.py:398-408).
+// ---------------------------------------------------------------------------
+template <typename T, bool HAS_PML, bool HAS_OBJ>
+__global__ __launch_bounds__(256) void bulk_E_generic(BulkArgs<T> a) {
+  const int64_t plane = (int64_t)a.ny * a.nz;
+  const int64_t ncell = (int64_t)(a.x1 - a.x0) * plane;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= ncell) return;
+  const int i = a.x0 + (int)(tid / plane);
+  const int64_t r = tid % plane;
+  const int j = (int)(r / a.nz);
+  const int k = (int)(r % a.nz);
+  const int64_t sz = 3, sy = 3 * (int64_t)a.nz, sx = 3 * plane;
+  const int64_t c3 = ((int64_t)i * plane + r) * 3;
+
+  const T* __restrict__ G = a.G;
+  const T hx = G[c3], hy = G[c3 + 1], hz = G[c3 + 2];
+  T d_y_z = 0, d_y_x = 0, d_z_y = 0, d_z_x = 0, d_x_z = 0, d_x_y = 0;
+  if (j > 0) { d_y_z = hz - G[c3 - sy + 2]; d_y_x = hx - G[c3 - sy]; }
+  if (k > 0) { d_z_y = hy - G[c3 - sz + 1]; d_z_x = hx - G[c3 - sz]; }
+  if (i > 0) { d_x_z = hz - G[c3 - sx + 2]; d_x_y = hy - G[c3 - sx + 1]; }
+  else if (a.ghost) { d_x_z = hz - a.ghost[r * 3 + 2]; d_x_y = hy - a.ghost[r * 3 + 1]; }
+  T cu[3];
+  cu[0] = d_y_z - d_z_y;
+  cu[1] = d_z_x - d_x_z;
+  cu[2] = d_x_y - d_y_x;
+
+  T e[3] = {a.F[c3], a.F[c3 + 1], a.F[c3 + 2]};
+  const T m[3] = {a.mat[c3], a.mat[c3 + 1], a.mat[c3 + 2]};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) e[c] += (a.sc * m[c]) * cu[c];
+
+  if (HAS_OBJ) {
+    for (int o = 0; o < a.nobj; ++o) {
+      const ObjK<T> O = a.obj[o];
+      if (i < O.x0 || i >= O.x1 || j < O.y0 || j >= O.y1 || k < O.z0 || k >= O.z1) continue;
+      const int64_t oc =
+          ((int64_t)(i - O.x0) * (O.y1 - O.y0) + (j - O.y0)) * (O.z1 - O.z0) + (k - O.z0);
+      if (O.kind == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) e[c] += (a.sc * O.inv[oc * 3 + c]) * cu[c];
+      } else if (O.kind == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const T f = O.absorb[oc * 3 + c];
+          e[c] *= (T(1) - f) / (T(1) + f);
+          e[c] += ((a.sc * O.inv[oc * 3 + c]) * cu[c]) / (T(1) + f);
+        }
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          const T* M = O.inv + oc * 9 + rr * 3;
+          T s = M[0] * cu[0];
+          s += M[1] * cu[1];
+          s += M[2] * cu[2];
+          e[rr] += a.sc * s;
+        }
+      }
+    }
+  }
+
+  if (HAS_PML) {
+    for (int p = 0; p < a.npml; ++p) {
+      const PmlK<T>& P = a.pml[p];
+      const int coord = P.axis == 0 ? i : (P.axis == 1 ? j : k);
+      const int l = coord - P.lo;
+      if (l < 0 || l >= P.t) continue;
+      const int li = P.axis == 0 ? l : i, lj = P.axis == 1 ? l : j, lk = P.axis == 2 ? l : k;
+      const int64_t s = ((int64_t)li * P.sy + lj) * P.sz + lk;
+      const int64_t slab = (int64_t)(P.axis == 0 ? P.t : a.nx) * P.sy * P.sz;
+      T dFu, dFv;
+      pml_pick<T>(P.axis, d_x_y, d_x_z, d_y_x, d_y_z, d_z_x, d_z_y, dFu, dFv);
+      const T b = P.b[l], cc = P.c[l];
+      T p0 = P.psi[s] * b, p1 = P.psi[slab + s] * b;
+      if (l >= 1) { p0 += dFv * cc; p1 += dFu * cc; }
+      P.psi[s] = p0;
+      P.psi[slab + s] = p1;
+      if (P.fused) {
+        const int u = (P.axis + 1) % 3, v = (P.axis + 2) % 3;
+        e[u] += (a.sc * m[u]) * (-p0);
+        e[v] += (a.sc * m[v]) * p1;
+      }
+    }
+  }
+  a.F[c3] = e[0];
+  a.F[c3 + 1] = e[1];
+  a.F[c3 + 2] = e[2];
+}
+
+// ---------------------------------------------------------------------------
+// H half step: PML memory update (reference fdtd/boundaries.py:450-476),
+// curl_E (fdtd/grid.py:29-51), H -= sc*inv_mu*curl (grid.py:309), PML
+// correction (boundaries.py:410-420).  Objects do nothing in this half step
+// (fdtd/objects.py:128-134, 220-226, 268-274).
+// ---------------------------------------------------------------------------
+template <typename T, bool HAS_PML>
+__global__ __launch_bounds__(256) void bulk_H_generic(BulkArgs<T> a) {
+  const int64_t plane = (int64_t)a.ny * a.nz;
+  const int64_t ncell = (int64_t)(a.x1 - a.x0) * plane;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= ncell) return;
+  const int i = a.x0 + (int)(tid / plane);
+  const int64_t r = tid % plane;
+  const int j = (int)(r / a.nz);
+  const int k = (int)(r % a.nz);
+  const int64_t sz = 3, sy = 3 * (int64_t)a.nz, sx = 3 * plane;
+  const int64_t c3 = ((int64_t)i * plane + r) * 3;
+
+  const T* __restrict__ G = a.G;
+  const T ex = G[c3], ey = G[c3 + 1], ez = G[c3 + 2];
+  T d_y_z = 0, d_y_x = 0, d_z_y = 0, d_z_x = 0, d_x_z = 0, d_x_y = 0;
+  if (j < a.ny - 1) { d_y_z = G[c3 + sy + 2] - ez; d_y_x = G[c3 + sy] - ex; }
+  if (k < a.nz - 1) { d_z_y = G[c3 + sz + 1] - ey; d_z_x = G[c3 + sz] - ex; }
+  if (i < a.nx - 1) { d_x_z = G[c3 + sx + 2] - ez; d_x_y = G[c3 + sx + 1] - ey; }
+  else if (a.ghost) { d_x_z = a.ghost[r * 3 + 2] - ez; d_x_y = a.ghost[r * 3 + 1] - ey; }
+  T cu[3];
+  cu[0] = d_y_z - d_z_y;
+  cu[1] = d_z_x - d_x_z;
+  cu[2] = d_x_y - d_y_x;
+
+  T h[3] = {a.F[c3], a.F[c3 + 1], a.F[c3 + 2]};
+  const T m[3] = {a.mat[c3], a.mat[c3 + 1], a.mat[c3 + 2]};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) h[c] -= (a.sc * m[c]) * cu[c];
+
+  if (HAS_PML) {
+    for (int p = 0; p < a.npml; ++p) {
+      const PmlK<T>& P = a.pml[p];
+      const int coord = P.axis == 0 ? i : (P.axis == 1 ? j : k);
+      const int l = coord - P.lo;
+      if (l < 0 || l >= P.t) continue;
+      const int li = P.axis == 0 ? l : i, lj = P.axis == 1 ? l : j, lk = P.axis == 2 ? l : k;
+      const int64_t s = ((int64_t)li * P.sy + lj) * P.sz + lk;
+      const int64_t slab = (int64_t)(P.axis == 0 ? P.t : a.nx) * P.sy * P.sz;
+      T dFu, dFv;
+      pml_pick<T>(P.axis, d_x_y, d_x_z, d_y_x, d_y_z, d_z_x, d_z_y, dFu, dFv);
+      const T b = P.b[l], cc = P.c[l];
+      T p0 = P.psi[s] * b, p1 = P.psi[slab + s] * b;
+      if (l <= P.t - 2) { p0 += dFv * cc; p1 += dFu * cc; }
+      P.psi[s] = p0;
+      P.psi[slab + s] = p1;
+      if (P.fused) {
+        const int u = (P.axis + 1) % 3, v = (P.axis + 2) % 3;
+        h[u] -= (a.sc * m[u]) * (-p0);
+        h[v] -= (a.sc * m[v]) * p1;
+      }
+    }
+  }
+  a.F[c3] = h[0];
+  a.F[c3 + 1] = h[1];
+  a.F[c3 + 2] = h[2];
+}
+
+// ---------------------------------------------------------------------------
+// Pieces that follow the bulk pass in boundary-list order.
+// ---------------------------------------------------------------------------
+
+// Field correction of a PML that was registered after a periodic boundary
+// (reference fdtd/boundaries.py:398-420); its memory variables were already
+// advanced by the bulk kernel.  sign = +1 for E, -1 for H.
+template <typename T>
+__global__ void pml_apply_slab(T* F, const T* mat, PmlK<T> P, int nx, int ny, int nz, T sc,
+                               T sign) {
+  const int sx = P.axis == 0 ? P.t : nx;
+  const int64_t slab = (int64_t)sx * P.sy * P.sz;
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= slab) return;
+  const int lk = (int)(s % P.sz);
+  const int lj = (int)((s / P.sz) % P.sy);
+  const int li = (int)(s / ((int64_t)P.sz * P.sy));
+  const int i = P.axis == 0 ? li + P.lo : li, j = P.axis == 1 ? lj + P.lo : lj,
+            k = P.axis == 2 ? lk + P.lo : lk;
+  const int64_t c3 = (((int64_t)i * ny + j) * nz + k) * 3;
+  const int u = (P.axis + 1) % 3, v = (P.axis + 2) % 3;
+  const T p0 = P.psi[s], p1 = P.psi[slab + s];
+  F[c3 + u] += sign * ((sc * mat[c3 + u]) * (-p0));
+  F[c3 + v] += sign * ((sc * mat[c3 + v]) * p1);
+}
+
+// Periodic copy of one plane (reference fdtd/boundaries.py:173-208):
+// F[dst along axis] = F[src along axis].
+template <typename T>
+__global__ void periodic_copy(T* F, int nx, int ny, int nz, int axis, int dst, int src) {
+  const int n1 = axis == 0 ? ny : nx;
+  const int n2 = axis == 2 ? ny : nz;
+  const int64_t total = (int64_t)n1 * n2 * 3;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int c = (int)(t % 3);
+  const int b = (int)((t / 3) % n2);
+  const int a = (int)(t / (3 * (int64_t)n2));
+  int64_t d, s;
+  if (axis == 0) {
+    d = (((int64_t)dst * ny + a) * nz + b) * 3 + c;
+    s = (((int64_t)src * ny + a) * nz + b) * 3 + c;
+  } else if (axis == 1) {
+    d = (((int64_t)a * ny + dst) * nz + b) * 3 + c;
+    s = (((int64_t)a * ny + src) * nz + b) * 3 + c;
+  } else {
+    d = (((int64_t)a * ny + b) * nz + dst) * 3 + c;
+    s = (((int64_t)a * ny + b) * nz + src) * 3 + c;
+  }
+  F[d] = F[s];
+}
+
+// Additive point list source (reference fdtd/sources.py:111, 336-337):
+// F[elem[p]] += profile[p] * w, evaluated in double and rounded once to T.
+// `serial` keeps the reference's sequential order when a cell is listed twice.
+template <typename T>
+__global__ void source_add_points(T* F, const int64_t* elem, const double* profile, double w,
+                                  int64_t n, int serial) {
+  if (serial) {
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      for (int64_t p = 0; p < n; ++p) F[elem[p]] += (T)(profile[p] * w);
+    return;
+  }
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) F[elem[p]] += (T)(profile[p] * w);
+}
+
+// Hard plane source (reference fdtd/sources.py:519, 525): F[box, comp] = value.
+template <typename T>
+__global__ void source_set_box(T* F, int ny, int nz, int x0, int x1, int y0, int y1, int z0,
+                               int z1, int comp, T value) {
+  const int bz = z1 - z0, by = y1 - y0;
+  const int64_t total = (int64_t)(x1 - x0) * by * bz;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int k = z0 + (int)(t % bz);
+  const int j = y0 + (int)((t / bz) % by);
+  const int i = x0 + (int)(t / ((int64_t)bz * by));
+  F[(((int64_t)i * ny + j) * nz + k) * 3 + comp] = value;
+}
+
+// Cell-list detector (reference fdtd/detectors.py:117, 123, 250, 263).
+template <typename T>
+__global__ void detect_cells(const T* F, const int64_t* cell, T* out, int64_t n) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 3) return;
+  out[t] = F[cell[t / 3] * 3 + (t % 3)];
+}
+
+// Loop-current detector (reference fdtd/detectors.py:443-462), including the
+// carry of the first layer's Hy term into the second layer (line 456) and
+// Python's wrap-around for index -1.
+template <typename T>
+__global__ void detect_current(const T* H, const int32_t* xyz, T* out, int64_t n, int nx, int ny,
+                               int nz, T spacing) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int px = xyz[3 * t], py = xyz[3 * t + 1], pz = xyz[3 * t + 2];
+  const int xm = px == 0 ? nx - 1 : px - 1;
+  const int ym = py == 0 ? ny - 1 : py - 1;
+  const int zm = pz == 0 ? nz - 1 : pz - 1;
+  auto at = [&](int i, int j, int k, int c) {
+    return H[(((int64_t)i * ny + j) * nz + k) * 3 + c];
+  };
+  T v1 = (at(px, ym, pz, 0) - at(px, py, pz, 0)) * spacing;
+  T v2 = (at(px, py, pz, 1) - at(xm, py, pz, 1)) * spacing;
+  const T cur1 = v1 + v2;
+  v1 = (at(px, ym, zm, 0) - at(px, py, zm, 0)) * spacing;
+  v2 += (at(px, py, zm, 1) - at(xm, py, zm, 1)) * spacing;
+  const T cur2 = v1 + v2;
+  out[t] = (cur1 + cur2) / T(2);
+}
+
+// Stand-alone curls (reference fdtd/grid.py:29-76).
+template <typename T, bool FORWARD>
+__global__ void curl_only(const T* G, T* out, int nx, int ny, int nz) {
+  const int64_t plane = (int64_t)ny * nz;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= plane * nx) return;
+  const int i = (int)(tid / plane);
+  const int64_t r = tid % plane;
+  const int j = (int)(r / nz), k = (int)(r % nz);
+  const int64_t sz = 3, sy = 3 * (int64_t)nz, sx = 3 * plane, c3 = tid * 3;
+  const T gx = G[c3], gy = G[c3 + 1], gz = G[c3 + 2];
+  T d_y_z = 0, d_y_x = 0, d_z_y = 0, d_z_x = 0, d_x_z = 0, d_x_y = 0;
+  if (FORWARD) {
+    if (j < ny - 1) { d_y_z = G[c3 + sy + 2] - gz; d_y_x = G[c3 + sy] - gx; }
+    if (k < nz - 1) { d_z_y = G[c3 + sz + 1] - gy; d_z_x = G[c3 + sz] - gx; }
+    if (i < nx - 1) { d_x_z = G[c3 + sx + 2] - gz; d_x_y = G[c3 + sx + 1] - gy; }
+  } else {
+    if (j > 0) { d_y_z = gz - G[c3 - sy + 2]; d_y_x = gx - G[c3 - sy]; }
+    if (k > 0) { d_z_y = gy - G[c3 - sz + 1]; d_z_x = gx - G[c3 - sz]; }
+    if (i > 0) { d_x_z = gz - G[c3 - sx + 2]; d_x_y = gy - G[c3 - sx + 1]; }
+  }
+  out[c3] = d_y_z - d_z_y;
+  out[c3 + 1] = d_z_x - d_x_z;
+  out[c3 + 2] = d_x_y - d_y_x;
+}
+
+}  // namespace fdtdhip

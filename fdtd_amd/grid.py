@@ -1,0 +1,345 @@
+"""The FDTD grid of the hip backend (counterpart of reference fdtd/grid.py).
+
+The grid owns the four field arrays as ordinary device tensors of shape
+``(Nx, Ny, Nz, 3)`` and a native *plan* (``libfdtd_hip``) that mirrors the Python
+lists ``boundaries / objects / sources / detectors``.  ``update_E`` /
+``update_H`` / ``run`` hand the whole half step (or many steps) to the plan;
+nothing of the time stepping is computed in Python or by torch operators.
+"""
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import constants as const
+from .backend import backend as bd
+from .typing_ import Number, Tuple
+
+
+def _is_int(v):
+    return isinstance(v, (int, np.integer)) and not isinstance(v, bool)
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _curl(field, forward):
+    if bd.staging or not torch.is_tensor(field) or not field.is_cuda:
+        raise RuntimeError("curl_E/curl_H of the hip backend need a tensor on the ROCm device")
+    if field.dim() != 4 or field.shape[-1] != 3:
+        raise ValueError("expected a field of shape (Nx, Ny, Nz, 3)")
+    if field.dtype not in (torch.float32, torch.float64):
+        raise ValueError("expected a float32 or float64 field")
+    f = field.contiguous()
+    out = torch.empty_like(f)
+    lib = _lib.load()
+    fn = lib.fdtdhip_curl_E if forward else lib.fdtdhip_curl_H
+    with torch.cuda.device(f.device):
+        _lib.check(fn(f.data_ptr(), out.data_ptr(), f.shape[0], f.shape[1], f.shape[2],
+                      _lib.F32 if f.dtype == torch.float32 else _lib.F64, _stream_ptr(f.device)))
+    return out
+
+
+def curl_E(E):
+    """Curl of an E-type field, located on the H points; forward differences, each one
+    dropped at the last index of its axis (reference fdtd/grid.py:29-51)."""
+    return _curl(E, True)
+
+
+def curl_H(H):
+    """Curl of an H-type field, located on the E points; backward differences, each one
+    dropped at index 0 of its axis (reference fdtd/grid.py:54-76)."""
+    return _curl(H, False)
+
+
+class Grid:
+    """The FDTD grid: fields, materials and the registered components
+    (reference fdtd/grid.py:80-169)."""
+
+    def __init__(
+        self,
+        shape: Tuple[Number, Number, Number],
+        grid_spacing: float = 155e-9,
+        permittivity: float = 1.0,
+        permeability: float = 1.0,
+        courant_number: float = None,
+    ):
+        self.grid_spacing = float(grid_spacing)
+        self.Nx, self.Ny, self.Nz = self._handle_tuple(shape)
+        self.D = int(self.Nx > 1) + int(self.Ny > 1) + int(self.Nz > 1)
+
+        limit = float(self.D) ** (-0.5)
+        if courant_number is None:
+            self.courant_number = 0.99 * limit  # small stability margin
+        elif courant_number > limit:
+            raise ValueError(
+                f"courant_number {courant_number} too high for a {self.D}D simulation"
+            )
+        else:
+            self.courant_number = float(courant_number)
+        self.time_step = self.courant_number * self.grid_spacing / const.c
+
+        full = (self.Nx, self.Ny, self.Nz, 3)
+        self.E = bd.zeros(full)
+        self.H = bd.zeros(full)
+        self.inverse_permittivity = bd.ones(full) / self._material(permittivity)
+        self.inverse_permeability = bd.ones(full) / self._material(permeability)
+
+        self.time_steps_passed = 0
+        self.sources = []
+        self.boundaries = []
+        self.detectors = []
+        self.objects = []
+        self.folder = None
+
+        self._plan = None
+        self._plan_signature = None
+        self._halo = (None, None)  # (H plane below, E plane above) of an x-slab
+
+    @staticmethod
+    def _material(value):
+        if bd.is_array(value):
+            value = bd.asarray(value)
+            if value.dim() == 3:
+                value = value[:, :, :, None]
+            return value
+        return float(value)
+
+    # ------------------------------------------------------------------ keys
+    def _handle_distance(self, distance: Number) -> int:
+        """Metres (any non-int) to a whole number of cells (reference fdtd/grid.py:171-175)."""
+        if _is_int(distance):
+            return int(distance)
+        return int(float(distance) / self.grid_spacing + 0.5)
+
+    def _handle_time(self, time: Number) -> int:
+        """Seconds (any non-int) to a whole number of time steps (reference fdtd/grid.py:177-181)."""
+        if _is_int(time):
+            return int(time)
+        return int(float(time) / self.time_step + 0.5)
+
+    def _handle_tuple(self, shape) -> Tuple[int, int, int]:
+        if len(shape) != 3:
+            raise ValueError(
+                f"invalid grid shape {shape}\n"
+                f"grid shape should be a 3D tuple containing floats or ints"
+            )
+        return tuple(self._handle_distance(s) for s in shape)
+
+    def _handle_slice(self, s: slice) -> slice:
+        conv = lambda v: self._handle_distance(v) if isinstance(v, float) else v
+        return slice(conv(s.start), conv(s.stop), conv(s.step))
+
+    def _handle_single_key(self, key):
+        """One entry of ``grid[x, y, z]`` to a slice or a list of cell indices
+        (reference fdtd/grid.py:213-223)."""
+        if isinstance(key, slice):
+            return self._handle_slice(key)
+        try:
+            return [self._handle_distance(k) for k in key]
+        except TypeError:
+            return [self._handle_distance(key)]
+
+    def __setitem__(self, key, attr):
+        if not isinstance(key, tuple):
+            key = (key,)
+        if len(key) > 3:
+            raise KeyError("maximum number of indices for the grid is 3")
+        x, y, z = tuple(key) + (slice(None),) * (3 - len(key))
+        attr._register_grid(
+            grid=self,
+            x=self._handle_single_key(x),
+            y=self._handle_single_key(y),
+            z=self._handle_single_key(z),
+        )
+
+    def _claim_name(self, thing):
+        """``grid.<name>`` access to named components (e.g. reference fdtd/boundaries.py:54-60)."""
+        if thing.name is None:
+            return
+        if hasattr(self, thing.name):
+            raise ValueError(f"The grid already has an attribute with name {thing.name}")
+        setattr(self, thing.name, thing)
+
+    # ------------------------------------------------------------ properties
+    @property
+    def x(self) -> float:
+        return self.Nx * self.grid_spacing
+
+    @property
+    def y(self) -> float:
+        return self.Ny * self.grid_spacing
+
+    @property
+    def z(self) -> float:
+        return self.Nz * self.grid_spacing
+
+    @property
+    def shape(self) -> Tuple[int, int, int]:
+        return (self.Nx, self.Ny, self.Nz)
+
+    @property
+    def time_passed(self) -> float:
+        return self.time_steps_passed * self.time_step
+
+    # ------------------------------------------------------------ native plan
+    def _fields(self):
+        """The four field tensors, made device-resident / contiguous / of the
+        backend precision if the user re-bound them to something else."""
+        out = []
+        full = (self.Nx, self.Ny, self.Nz, 3)
+        for name in ("E", "H", "inverse_permittivity", "inverse_permeability"):
+            t = getattr(self, name)
+            if not torch.is_tensor(t):
+                t = bd.array(t)
+            if tuple(t.shape) != full:
+                t = torch.broadcast_to(t, full)
+            if t.device != bd.device or t.dtype != bd.float or not t.is_contiguous():
+                t = t.to(device=bd.device, dtype=bd.float).contiguous()
+            if t is not getattr(self, name):
+                setattr(self, name, t)
+            out.append(t)
+        return out
+
+    def _signature(self):
+        sig = [bd.float, bd.device]
+        for group in (self.boundaries, self.objects, self.sources, self.detectors):
+            sig.append(tuple(t._signature() for t in group))
+        return tuple(sig)
+
+    def _ensure_plan(self):
+        if bd.staging:
+            raise RuntimeError(
+                "this grid lives in host staging memory: time stepping needs the hip "
+                "backend on a ROCm device (fdtd_amd.set_backend('hip'))"
+            )
+        lib = _lib.load()
+        if self._plan is None:
+            handle = ctypes.c_void_p()
+            _lib.check(lib.fdtdhip_plan_create(
+                ctypes.byref(handle), self.Nx, self.Ny, self.Nz, bd.native_dtype,
+                self.courant_number, bd.device.index or 0))
+            self._plan = handle
+            self._plan_signature = None
+        E, H, ie, im = self._fields()
+        sig = self._signature()
+        if sig != self._plan_signature:
+            _lib.check(lib.fdtdhip_plan_reset(self._plan))
+            for group in (self.boundaries, self.objects, self.sources, self.detectors):
+                for thing in group:
+                    thing._native_add(lib, self._plan)
+            self._plan_signature = sig
+        _lib.check(lib.fdtdhip_plan_set_stream(self._plan, _stream_ptr(bd.device)))
+        _lib.check(lib.fdtdhip_plan_set_fields(
+            self._plan, E.data_ptr(), H.data_ptr(), ie.data_ptr(), im.data_ptr()))
+        lo, hi = self._halo
+        _lib.check(lib.fdtdhip_plan_set_halo(
+            self._plan, lo.data_ptr() if lo is not None else None,
+            hi.data_ptr() if hi is not None else None))
+        return lib
+
+    def __del__(self):
+        plan, self._plan = getattr(self, "_plan", None), None
+        if plan is not None:
+            try:
+                _lib.load().fdtdhip_plan_destroy(plan)
+            except Exception:
+                pass
+
+    # --------------------------------------------------------------- stepping
+    def update_E(self):
+        """One electric half step (reference fdtd/grid.py:275-299)."""
+        lib = self._ensure_plan()
+        for det in self.detectors:
+            det._reserve(lib, self._plan, 1, 0)
+        _lib.check(lib.fdtdhip_update_E(self._plan, self.time_steps_passed))
+        for det in self.detectors:
+            det._commit(1, 0)
+
+    def update_H(self):
+        """One magnetic half step (reference fdtd/grid.py:301-325)."""
+        lib = self._ensure_plan()
+        for det in self.detectors:
+            det._reserve(lib, self._plan, 0, 1)
+        _lib.check(lib.fdtdhip_update_H(self._plan, self.time_steps_passed))
+        for det in self.detectors:
+            det._commit(0, 1)
+
+    def step(self):
+        """One full step: E half step, H half step (reference fdtd/grid.py:267-273)."""
+        self._advance(1)
+
+    def _advance(self, n):
+        if n <= 0:
+            return
+        lib = self._ensure_plan()
+        for det in self.detectors:
+            det._reserve(lib, self._plan, n, n)
+        _lib.check(lib.fdtdhip_run(self._plan, self.time_steps_passed, n))
+        for det in self.detectors:
+            det._commit(n, n)
+        self.time_steps_passed += n
+
+    def run(self, total_time: Number, progress_bar: bool = True):
+        """Advance by ``total_time`` (int: steps, float: seconds), reference fdtd/grid.py:250-265.
+
+        The steps are enqueued on the device without host synchronisation; with
+        ``progress_bar`` the bar advances per enqueued chunk.
+        """
+        if isinstance(total_time, float):
+            total_time /= self.time_step
+        steps = int(total_time)
+        if steps <= 0:
+            return
+        if not progress_bar:
+            self._advance(steps)
+            return
+        from tqdm import tqdm
+
+        chunk = max(1, steps // 50)
+        with tqdm(total=steps) as bar:
+            done = 0
+            while done < steps:
+                n = min(chunk, steps - done)
+                self._advance(n)
+                torch.cuda.current_stream(bd.device).synchronize()
+                bar.update(n)
+                done += n
+
+    def reset(self):
+        """Zero the fields and the step counter; boundary memory and detector
+        readings are kept, as in the reference (fdtd/grid.py:327-333)."""
+        self.H = torch.zeros_like(self.H.detach())
+        self.E = torch.zeros_like(self.E.detach())
+        self.time_steps_passed *= 0
+
+    # ----------------------------------------------------------------- text
+    def __repr__(self):
+        return (
+            f"{self.__class__.__name__}(shape=({self.Nx},{self.Ny},{self.Nz}), "
+            f"grid_spacing={self.grid_spacing:.2e}, courant_number={self.courant_number:.2f})"
+        )
+
+    def __str__(self):
+        text = repr(self) + "\n"
+        for title, group in (("sources", self.sources), ("detectors", self.detectors),
+                             ("boundaries", self.boundaries), ("objects", self.objects)):
+            if group:
+                text += f"\n{title}:\n" + "".join(str(t) for t in group)
+        return text
+
+
+def _fmt_slice(s):
+    if not isinstance(s, slice):
+        return str(s)
+    a = "" if s.start is None else str(s.start)
+    b = "" if s.stop is None else str(s.stop)
+    return f"{a}:{b}"
+
+
+def describe_location(x, y, z):
+    """`` @ x=..., y=..., z=...`` line used by the components' ``__str__``."""
+    return f"        @ x={_fmt_slice(x)}, y={_fmt_slice(y)}, z={_fmt_slice(z)}\n"

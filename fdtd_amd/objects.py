@@ -1,0 +1,181 @@
+"""Objects of the hip backend (counterpart of reference fdtd/objects.py).
+
+An object is a box with its own inverse-permittivity array.  Registration does
+what the reference does on the host side -- build the array, copy the grid's
+border values onto the far faces, zero the grid's inverse permittivity inside
+the box (reference fdtd/objects.py:60-90) -- using device tensors; the per-step
+arithmetic (reference fdtd/objects.py:116-126, 204-218, 251-266) runs inside the
+native E half-step kernel, which applies the objects in registration order.
+"""
+
+import ctypes
+
+import torch
+
+from . import _lib
+from . import constants as const
+from .backend import backend as bd
+from .grid import Grid, describe_location
+from .typing_ import ListOrSlice, Tensorlike
+
+
+class Object:
+    """Isotropic (per-component) dielectric box."""
+
+    _native_kind = _lib.OBJ_ISOTROPIC
+
+    def __init__(self, permittivity: Tensorlike, name: str = None):
+        self.grid = None
+        self.name = name
+        self.permittivity = permittivity
+
+    def _register_grid(self, grid: Grid, x: ListOrSlice, y: ListOrSlice, z: ListOrSlice):
+        self.grid = grid
+        grid.objects.append(self)
+        grid._claim_name(self)
+        self.x = self._handle_slice(x, max_index=grid.Nx)
+        self.y = self._handle_slice(y, max_index=grid.Ny)
+        self.z = self._handle_slice(z, max_index=grid.Nz)
+        self.Nx = abs(self.x.stop - self.x.start)
+        self.Ny = abs(self.y.stop - self.y.start)
+        self.Nz = abs(self.z.stop - self.z.start)
+
+        perm = self.permittivity
+        if bd.is_array(perm):
+            perm = bd.asarray(perm)
+            if perm.dim() == 3:
+                perm = perm[:, :, :, None]
+            self.permittivity = perm
+        inv = bd.ones((self.Nx, self.Ny, self.Nz, 3)) / perm
+
+        # far faces take the grid's border value so that the object is symmetric
+        gi = grid.inverse_permittivity
+        if self.Nx > 1:
+            inv[-1, :, :, 0] = gi[-1, self.y, self.z, 0]
+        if self.Ny > 1:
+            inv[:, -1, :, 1] = gi[self.x, -1, self.z, 1]
+        if self.Nz > 1:
+            inv[:, :, -1, 2] = gi[self.x, self.y, -1, 2]
+        self.inverse_permittivity = inv
+
+        gi[self.x, self.y, self.z] = 0  # the grid's own update adds nothing inside the box
+
+    def _handle_slice(self, s: ListOrSlice, max_index: int = None) -> slice:
+        if isinstance(s, list):
+            if len(s) != 1:
+                raise IndexError(
+                    "One can only use slices or single indices to index the grid for an Object"
+                )
+            return slice(s[0], s[0] + 1, None)
+        if not isinstance(s, slice):
+            raise ValueError("Invalid grid indexing used for object")
+        if s.step is not None and s.step != 1:
+            raise IndexError("Can only use slices with unit step to index the grid for an Object")
+        start = 0 if s.start is None else s.start
+        stop = max_index if s.stop is None else s.stop
+        if start < 0:
+            start += max_index
+        if stop < 0:
+            stop += max_index
+        return slice(start, stop, None)
+
+    # hooks of the reference's step loop; the native plan does the work
+    def update_E(self, curl_H=None):
+        pass
+
+    def update_H(self, curl_E=None):
+        pass
+
+    # -------------------------------------------------------------- native
+    def _box(self):
+        return [self.x.start, self.x.stop, self.y.start, self.y.stop, self.z.start, self.z.stop]
+
+    def _tensor(self, name):
+        t = getattr(self, name)
+        if t.device != bd.device or t.dtype != bd.float or not t.is_contiguous():
+            keep_grad = t.requires_grad
+            t = t.detach().to(device=bd.device, dtype=bd.float).contiguous()
+            t.requires_grad_(keep_grad)
+            setattr(self, name, t)
+        return t
+
+    def _signature(self):
+        return (type(self).__name__, id(self), tuple(self._box()),
+                self._tensor("inverse_permittivity").data_ptr())
+
+    def _native_add(self, lib, plan):
+        _lib.check(lib.fdtdhip_plan_add_object(
+            plan, self._native_kind, _lib.int32s(self._box()),
+            ctypes.c_void_p(self._tensor("inverse_permittivity").data_ptr()), None))
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(name={repr(self.name)})"
+
+    def __str__(self):
+        return "    " + repr(self) + "\n" + describe_location(self.x, self.y, self.z)
+
+
+class AbsorbingObject(Object):
+    """Dielectric box with conductivity (loss)."""
+
+    _native_kind = _lib.OBJ_ABSORBING
+
+    def __init__(self, permittivity: Tensorlike, conductivity: Tensorlike, name: str = None):
+        super().__init__(permittivity, name)
+        self.conductivity = conductivity
+
+    def _register_grid(self, grid: Grid, x: slice = None, y: slice = None, z: slice = None):
+        super()._register_grid(grid=grid, x=x, y=y, z=z)
+        cond = bd.asarray(self.conductivity)
+        while cond.dim() < self.inverse_permittivity.dim():
+            cond = cond[..., None]
+        self.conductivity = torch.broadcast_to(cond, self.inverse_permittivity.shape)
+        # reference fdtd/objects.py:195-202, same left-to-right products
+        self.absorption_factor = (
+            0.5
+            * grid.courant_number
+            * self.inverse_permittivity
+            * self.conductivity
+            * grid.grid_spacing
+            * const.eta0
+        )
+
+    def _signature(self):
+        return super()._signature() + (self._tensor("absorption_factor").data_ptr(),)
+
+    def _native_add(self, lib, plan):
+        _lib.check(lib.fdtdhip_plan_add_object(
+            plan, self._native_kind, _lib.int32s(self._box()),
+            ctypes.c_void_p(self._tensor("inverse_permittivity").data_ptr()),
+            ctypes.c_void_p(self._tensor("absorption_factor").data_ptr())))
+
+
+class AnisotropicObject(Object):
+    """Box with a full 3x3 inverse-permittivity tensor per cell; starts diagonal, the
+    user may fill the off-diagonals afterwards (reference fdtd/objects.py:229-266)."""
+
+    _native_kind = _lib.OBJ_ANISOTROPIC
+
+    def _register_grid(self, grid: Grid, x: slice = None, y: slice = None, z: slice = None):
+        super()._register_grid(grid=grid, x=x, y=y, z=z)
+        self.inverse_permittivity = torch.diag_embed(self.inverse_permittivity).contiguous()
+
+
+class LearnableAnisotropicObject(AnisotropicObject):
+    """Anisotropic box whose tensor is a leaf that collects gradients
+    (reference fdtd/objects.py:276-349 with ``is_substrate=False``)."""
+
+    def __init__(self, permittivity: Tensorlike, is_substrate=False, name: str = None, device=None):
+        super().__init__(permittivity, name)
+        if is_substrate:
+            raise NotImplementedError(
+                "the energy-dependent substrate modifier (is_substrate=True) is not part of "
+                "the hip backend"
+            )
+        self.is_substrate = False
+        self.device = device
+
+    def _register_grid(self, grid: Grid, x: slice = None, y: slice = None, z: slice = None):
+        super()._register_grid(grid=grid, x=x, y=y, z=z)
+        self.inverse_permittivity.requires_grad = True
+        self.inverse_permittivity.retain_grad()

@@ -1,0 +1,255 @@
+"""Sources of the hip backend (counterpart of reference fdtd/sources.py).
+
+A source resolves its location and spatial profile on the host at registration;
+the per-step waveform value is evaluated by the native library in C (same libm
+as CPython, same expression order as reference fdtd/sources.py:97-110) and the
+injection is a small device kernel that runs after the boundaries of the same
+half step (reference fdtd/grid.py:293-295, 319-321).
+"""
+
+import numpy as np
+
+from . import _lib
+from .grid import Grid
+from .typing_ import List, ListOrSlice, Number, Tuple
+
+
+def _line_indices(grid, x, y, z, convert):
+    """Cells on the diagonal of the box spanned by the keys: ``max |extent|`` points
+    from ``linspace(start, stop, endpoint=False)`` truncated to int, shared by
+    line sources and line detectors (reference fdtd/sources.py:265-314,
+    fdtd/detectors.py:81-112)."""
+    conv = grid._handle_distance if convert else (lambda v: v)
+    if isinstance(x, list) and isinstance(y, list) and isinstance(z, list):
+        if not (len(x) == len(y) == len(z)):
+            raise IndexError(
+                "sources require grid to be indexed with slices or equal length list-indices"
+            )
+        return [conv(v) for v in x], [conv(v) for v in y], [conv(v) for v in z]
+    ends = []
+    for key, n in ((x, grid.Nx), (y, grid.Ny), (z, grid.Nz)):
+        if isinstance(key, list):
+            key = slice(conv(key[0]), conv(key[-1]), None)
+        a = conv(key.start if key.start is not None else 0)
+        b = conv(key.stop if key.stop is not None else n)
+        ends.append((a, b))
+    m = max(abs(b - a) for a, b in ends)
+    return m, [[int(v) for v in np.linspace(a, b, m, endpoint=False).astype(np.int64)]
+               if m > 0 else [] for a, b in ends]
+
+
+class _Waveform:
+    """Carrier parameters common to point and line sources."""
+
+    def _init_wave(self, period, amplitude, phase_shift, pulse, cycle, hanning_dt):
+        self.period = period
+        self.amplitude = amplitude
+        self.phase_shift = phase_shift
+        self.pulse = pulse
+        self.cycle = cycle
+        self.frequency = 1.0 / period  # from the period as given (reference fdtd/sources.py:60)
+        self.hanning_dt = hanning_dt if hanning_dt is not None else 0.5 / self.frequency
+
+    def _wave_signature(self):
+        return (self.period, self.phase_shift, bool(self.pulse), self.cycle, self.frequency,
+                self.hanning_dt)
+
+    def _wave_args(self):
+        return (float(self.period), float(self.phase_shift), int(bool(self.pulse)),
+                float(self.frequency), float(self.hanning_dt), float(self.cycle))
+
+    def update_E(self):
+        pass
+
+    def update_H(self):
+        pass
+
+
+class PointSource(_Waveform):
+    """Soft source adding to Ez of a single cell (reference fdtd/sources.py:26-131)."""
+
+    def __init__(self, period: Number = 15, amplitude: float = 1.0, phase_shift: float = 0.0,
+                 name: str = None, pulse: bool = False, cycle: int = 5,
+                 hanning_dt: float = 10.0, verbose=False):
+        self.grid = None
+        self.name = name
+        self.verbose = verbose
+        self._init_wave(period, amplitude, phase_shift, pulse, cycle, hanning_dt)
+
+    def _register_grid(self, grid: Grid, x: Number, y: Number, z: Number):
+        self.grid = grid
+        grid.sources.append(self)
+        grid._claim_name(self)
+        try:
+            (x,), (y,), (z,) = x, y, z
+        except (TypeError, ValueError):
+            raise ValueError("a point source should be placed on a single grid cell.")
+        self.x, self.y, self.z = grid._handle_tuple((x, y, z))
+        self.period = grid._handle_time(self.period)
+
+    def _signature(self):
+        return ("point", id(self), self.x, self.y, self.z, self.amplitude) + self._wave_signature()
+
+    def _native_add(self, lib, plan):
+        g = self.grid
+        cell = [self.x % g.Nx, self.y % g.Ny, self.z % g.Nz]  # negative indices wrap like Python
+        _lib.check(lib.fdtdhip_plan_add_source(
+            plan, _lib.SRC_ADD_POINTS, 2, 2, 1, _lib.int32s(cell),
+            _lib.doubles([self.amplitude]), *self._wave_args()))
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(period={self.period}, amplitude={self.amplitude}, "
+                f"phase_shift={self.phase_shift}, name={repr(self.name)})")
+
+    def __str__(self):
+        return "    " + repr(self) + "\n" + f"        @ x={self.x}, y={self.y}, z={self.z}\n"
+
+
+class LineSource(_Waveform):
+    """Soft source adding to Ez along a line with a Gaussian profile whose sum is the
+    amplitude (reference fdtd/sources.py:170-355)."""
+
+    def __init__(self, period: Number = 15, amplitude: float = 1.0, phase_shift: float = 0.0,
+                 name: str = None, pulse: bool = False, cycle: int = 5,
+                 hanning_dt: float = 10.0):
+        self.grid = None
+        self.name = name
+        self._init_wave(period, amplitude, phase_shift, pulse, cycle, hanning_dt)
+
+    def _register_grid(self, grid: Grid, x: ListOrSlice, y: ListOrSlice, z: ListOrSlice):
+        self.grid = grid
+        grid.sources.append(self)
+        grid._claim_name(self)
+        self.x, self.y, self.z = self._handle_slices(x, y, z)
+        self.period = grid._handle_time(self.period)
+
+        mid = len(self.x) // 2
+        r2 = np.array(
+            (np.array(self.x) - self.x[mid]) ** 2
+            + (np.array(self.y) - self.y[mid]) ** 2
+            + (np.array(self.z) - self.z[mid]) ** 2,
+            np.float64,
+        )
+        profile = np.exp(-(r2 ** 2) / (2 * (0.5 * r2.max()) ** 2))
+        profile /= profile.sum()
+        profile *= self.amplitude
+        self.profile = profile  # host float64; uploaded with the plan
+
+    def _handle_slices(self, x, y, z) -> Tuple[List, List, List]:
+        res = _line_indices(self.grid, x, y, z, convert=True)
+        if len(res) == 3:
+            return res
+        m, (xs, ys, zs) = res
+        if m < 2:
+            raise ValueError("a LineSource should consist of at least two gridpoints")
+        return xs, ys, zs
+
+    def _signature(self):
+        return ("line", id(self), tuple(self.x), tuple(self.y), tuple(self.z),
+                self.profile.tobytes()) + self._wave_signature()
+
+    def _native_add(self, lib, plan):
+        g = self.grid
+        cells = []
+        for x, y, z in zip(self.x, self.y, self.z):
+            cells += [x % g.Nx, y % g.Ny, z % g.Nz]
+        _lib.check(lib.fdtdhip_plan_add_source(
+            plan, _lib.SRC_ADD_POINTS, 2, 2, len(self.x), _lib.int32s(cells),
+            _lib.doubles(self.profile), *self._wave_args()))
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(period={self.period}, amplitude={self.amplitude}, "
+                f"phase_shift={self.phase_shift}, name={repr(self.name)})")
+
+    def __str__(self):
+        loc = ", ".join(f"{n}=[{v[0]}, ... , {v[-1]}]" for n, v in
+                        (("x", self.x), ("y", self.y), ("z", self.z)))
+        return "    " + repr(self) + "\n" + f"        @ {loc}\n"
+
+
+class PlaneSource:
+    """Hard source: overwrites one E component and one H component on a plane with
+    ``amplitude * sin(...)`` every half step (reference fdtd/sources.py:359-540)."""
+
+    def __init__(self, period: Number = 15, amplitude: float = 1.0, phase_shift: float = 0.0,
+                 name: str = None, polarization: str = "z"):
+        self.grid = None
+        self.period = period
+        self.amplitude = amplitude
+        self.phase_shift = phase_shift
+        self.name = name
+        self.polarization = polarization
+
+    def _register_grid(self, grid: Grid, x: ListOrSlice, y: ListOrSlice, z: ListOrSlice):
+        self.grid = grid
+        grid.sources.append(self)
+        grid._claim_name(self)
+        try:
+            self.x, self.y, self.z = self._handle_slices(x, y, z)
+        except ValueError:
+            grid.sources.remove(self)
+            raise
+        self.period = grid._handle_time(self.period)
+        shape = (self.x.stop - self.x.start, self.y.stop - self.y.start, self.z.stop - self.z.start)
+        self.profile = self.amplitude * np.ones(shape)
+
+    def _handle_slices(self, x, y, z):
+        g = self.grid
+        spans = []
+        for key, n in ((x, g.Nx), (y, g.Ny), (z, g.Nz)):
+            if not isinstance(key, slice):
+                if isinstance(key, list):
+                    (key,) = key
+                c = g._handle_distance(key)
+                key = slice(c, c + 1, None)
+            a = g._handle_distance(key.start if key.start is not None else 0)
+            b = g._handle_distance(key.stop if key.stop is not None else n)
+            spans.append(slice(a, b) if a < b else (slice(b, a) if a > b else slice(a, a + 1)))
+        extents = [s.stop - s.start for s in spans]
+        if extents.count(0) > 0:
+            raise ValueError("Given location for PlaneSource results in slices of length 0!")
+        if extents.count(1) == 0:
+            raise ValueError("Given location for PlaneSource is not a 2D plane!")
+        if extents.count(1) > 1:
+            raise ValueError(
+                "Given location for PlaneSource should have no more than one dimension in "
+                "which it's flat.\nUse a LineSource for lower dimensional sources."
+            )
+        self._Epol = "xyz".index(self.polarization)
+        if extents[self._Epol] == 1:
+            raise ValueError(
+                "PlaneSource cannot be polarized perpendicular to the orientation of the plane."
+            )
+        # H component: transverse to E and to the propagation direction
+        # (table of reference fdtd/sources.py:507-511)
+        probe, first, second = [(2, 1, 2), (2, 0, 2), (1, 0, 1)][self._Epol]
+        self._Hpol = first if extents[probe] == 1 else second
+        return tuple(spans)
+
+    def update_E(self):
+        pass
+
+    def update_H(self):
+        pass
+
+    def _signature(self):
+        return ("plane", id(self), self.x.start, self.x.stop, self.y.start, self.y.stop,
+                self.z.start, self.z.stop, self._Epol, self._Hpol, self.period,
+                self.amplitude, self.phase_shift)
+
+    def _native_add(self, lib, plan):
+        box = [self.x.start, self.x.stop, self.y.start, self.y.stop, self.z.start, self.z.stop]
+        _lib.check(lib.fdtdhip_plan_add_source(
+            plan, _lib.SRC_SET_BOX, self._Epol, self._Hpol, 1, _lib.int32s(box),
+            _lib.doubles([self.amplitude]), float(self.period), float(self.phase_shift),
+            0, 0.0, 0.0, 1.0))
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(period={self.period}, amplitude={self.amplitude}, "
+                f"phase_shift={self.phase_shift}, name={repr(self.name)}, "
+                f"polarization={repr(self.polarization)})")
+
+    def __str__(self):
+        loc = ", ".join(f"{n}=[{s.start}, ... , {s.stop}]" for n, s in
+                        (("x", self.x), ("y", self.y), ("z", self.z)))
+        return "    " + repr(self) + "\n" + f"        @ {loc}\n"

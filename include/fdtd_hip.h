@@ -1,0 +1,179 @@
+/*
+ * fdtd_hip.h -- C ABI of the MI355X (gfx950) Yee time-stepping engine.
+ *
+ * The reference (simenhu/fdtd) is pure Python and has no FFI; its seam for a
+ * new device is the array backend swapped by set_backend() (reference
+ * fdtd/backend.py:354-426) together with the half-step methods of the Grid
+ * (reference fdtd/grid.py:250-325).  Every entry point below names the piece of
+ * reference code it stands in for.
+ *
+ * Conventions
+ *   - All functions return 0 on success and a negative code on failure;
+ *     fdtdhip_last_error() returns the message of the last failure on the
+ *     calling thread.
+ *   - Field memory is CALLER OWNED device memory, C-contiguous
+ *     (nx, ny, nz, 3) arrays of the plan's element type, the layout of the
+ *     reference's Grid.E / Grid.H / Grid.inverse_permittivity /
+ *     Grid.inverse_permeability (reference fdtd/grid.py:135-151).  The plan
+ *     only borrows the pointers.
+ *   - Small read-only tables (PML profiles, index lists, object descriptors)
+ *     are copied into device memory owned by the plan when they are added.
+ *   - A plan is not thread safe.  All work is enqueued on the plan's stream
+ *     (fdtdhip_plan_set_stream); no call synchronises the device except
+ *     fdtdhip_plan_destroy and fdtdhip_plan_reset.
+ */
+#ifndef FDTD_HIP_H
+#define FDTD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDTDHIP_ABI_VERSION 1
+
+/* element types (reference: backend.float, fdtd/backend.py:403,415) */
+#define FDTDHIP_F32 0
+#define FDTDHIP_F64 1
+
+/* object kinds (reference fdtd/objects.py: Object 27, AbsorbingObject 160,
+ * AnisotropicObject 229 / LearnableAnisotropicObject 276 with is_substrate=False) */
+#define FDTDHIP_OBJ_ISOTROPIC 0
+#define FDTDHIP_OBJ_ABSORBING 1
+#define FDTDHIP_OBJ_ANISOTROPIC 2
+
+/* source kinds (reference fdtd/sources.py: PointSource 26 / LineSource 170 add to
+ * one component at a list of cells; PlaneSource 359 overwrites a box) */
+#define FDTDHIP_SRC_ADD_POINTS 0
+#define FDTDHIP_SRC_SET_BOX 1
+
+/* detector kinds (reference fdtd/detectors.py: LineDetector 20 and BlockDetector
+ * 146 copy the three components of listed cells; CurrentDetector 284) */
+#define FDTDHIP_DET_CELLS 0
+#define FDTDHIP_DET_CURRENT 1
+
+typedef struct fdtdhip_plan fdtdhip_plan;
+
+int fdtdhip_abi_version(void);
+const char* fdtdhip_last_error(void);
+
+/* Number of visible HIP devices (0 when there is none); stands in for the
+ * availability check of set_backend (reference fdtd/backend.py:378-385). */
+int fdtdhip_device_count(void);
+
+/* One plan per Grid (reference fdtd/grid.py:90-169).  `courant` is
+ * Grid.courant_number; (nx, ny, nz) is the extent of the arrays this plan works
+ * on (one x-slab of a decomposed grid, or the whole grid). */
+int fdtdhip_plan_create(fdtdhip_plan** out, int nx, int ny, int nz, int dtype,
+                        double courant, int device);
+int fdtdhip_plan_destroy(fdtdhip_plan* plan);
+
+/* Forget every boundary, object, source and detector (used when the Python
+ * lists of the Grid changed, reference fdtd/grid.py:157-166). */
+int fdtdhip_plan_reset(fdtdhip_plan* plan);
+
+/* HIP stream (hipStream_t) on which all later work of the plan is enqueued. */
+int fdtdhip_plan_set_stream(fdtdhip_plan* plan, void* stream);
+
+/* Borrow the four field arrays (reference fdtd/grid.py:135-151). */
+int fdtdhip_plan_set_fields(fdtdhip_plan* plan, void* E, void* H,
+                            const void* inv_permittivity, const void* inv_permeability);
+
+/* x-slab decomposition (no reference counterpart: the reference is single
+ * device).  `H_below`: (ny,nz,3) copy of the neighbour's last H plane, used by
+ * update_E for plane 0 instead of the domain-edge mask of reference
+ * fdtd/grid.py:71,73.  `E_above`: the neighbour's first E plane, used by
+ * update_H for the last plane instead of the mask of fdtd/grid.py:46,48.
+ * NULL = true domain edge. */
+int fdtdhip_plan_set_halo(fdtdhip_plan* plan, const void* H_below, const void* E_above);
+
+/* PML slab (reference fdtd/boundaries.py:356-476).  axis 0..2, side 0 = low /
+ * 1 = high, `thickness` cells.  bE,cE,bH,cH: HOST arrays of `thickness`
+ * doubles, the normal-axis component of the reference's bE/cE/bH/cH
+ * (boundaries.py:384-396).  psiE / psiH: caller-owned, zero-initialised device
+ * arrays of shape (2, slab cells): the two recursive-convolution memory
+ * variables that can be non-zero for this face, [0] = psi_{E,u}[..., axis],
+ * [1] = psi_{E,v}[..., axis] with u = (axis+1)%3, v = (axis+2)%3
+ * (boundaries.py:437-444, 465-472).  Boundaries act in the order added
+ * (grid.py:279-291). */
+int fdtdhip_plan_add_pml(fdtdhip_plan* plan, int axis, int side, int thickness,
+                         const double* bE, const double* cE, const double* bH,
+                         const double* cH, void* psiE, void* psiH);
+
+/* Periodic boundary along `axis` (reference fdtd/boundaries.py:173-208). */
+int fdtdhip_plan_add_periodic(fdtdhip_plan* plan, int axis);
+
+/* Object occupying box = {x0,x1,y0,y1,z0,z1} (reference fdtd/objects.py:116-126,
+ * 204-218, 251-266).  inv: device (bx,by,bz,3), or (bx,by,bz,3,3) for
+ * FDTDHIP_OBJ_ANISOTROPIC.  absorb: device (bx,by,bz,3) absorption factor
+ * (objects.py:195-202) for FDTDHIP_OBJ_ABSORBING, else NULL.  The caller has
+ * already zeroed the grid's inverse permittivity in the box (objects.py:90). */
+int fdtdhip_plan_add_object(fdtdhip_plan* plan, int kind, const int32_t box[6],
+                            const void* inv, const void* absorb);
+
+/* Source.  FDTDHIP_SRC_ADD_POINTS: cells = HOST array of 3*n ints (x,y,z per
+ * point), profile = HOST array of n doubles; each step E[cell, comp_E] +=
+ * profile[i]*w(q) (reference fdtd/sources.py:95-111, 316-337).
+ * FDTDHIP_SRC_SET_BOX: cells = 6 ints {x0,x1,y0,y1,z0,z1}, n = 1,
+ * profile[0] = amplitude; E[box, comp_E] = amplitude*w(q) in update_E and
+ * H[box, comp_H] = amplitude*w(q) in update_H (sources.py:515-525).
+ * w(q) = sin(2*pi*q/period + phase), or with pulse != 0 the Hanning pulse
+ * hanning(frequency, q*hanning_dt, cycle) for q < int(2*pi/(frequency*hanning_dt/cycle)),
+ * else 0 (sources.py:99-110; waveforms.py:8-9). */
+int fdtdhip_plan_add_source(fdtdhip_plan* plan, int kind, int comp_E, int comp_H,
+                            int64_t n, const int32_t* cells, const double* profile,
+                            double period, double phase, int pulse, double frequency,
+                            double hanning_dt, double cycle);
+
+/* Detector over n points.  FDTDHIP_DET_CELLS: cells = HOST 3*n ints; each
+ * reading is (n,3) (reference fdtd/detectors.py:114-124, 241-265).
+ * FDTDHIP_DET_CURRENT: each reading is (n) loop currents (detectors.py:443-462),
+ * `spacing` = Grid.grid_spacing.  Returns the detector id (>= 0). */
+int fdtdhip_plan_add_detector(fdtdhip_plan* plan, int kind, int64_t n,
+                              const int32_t* cells, double spacing);
+
+/* Where the next `capacity` readings of detector `id` go: device arrays of
+ * capacity*(n*3) (outE, outH; FDTDHIP_DET_CELLS) or capacity*n (outH only;
+ * FDTDHIP_DET_CURRENT) elements.  Stands in for the Python lists detector.E /
+ * detector.H / detector.I (detectors.py:31-32, 319).  Each update_E / update_H
+ * consumes one reading; running out of capacity is an error. */
+int fdtdhip_plan_set_detector_output(fdtdhip_plan* plan, int id, void* outE, void* outH,
+                                     int64_t capacity);
+
+/* Half steps (reference fdtd/grid.py:275-299 and 301-325); q =
+ * Grid.time_steps_passed. */
+int fdtdhip_update_E(fdtdhip_plan* plan, int64_t q);
+int fdtdhip_update_H(fdtdhip_plan* plan, int64_t q);
+
+/* The same half steps split for overlap with a halo exchange: `_bulk` is the
+ * fused curl + material + object + PML pass over x planes [x0, x1); `_post`
+ * is everything that follows it (periodic copies, PMLs registered after a
+ * periodic boundary, sources, detectors). update_X = bulk(0,nx) + post. */
+int fdtdhip_update_E_bulk(fdtdhip_plan* plan, int x0, int x1);
+int fdtdhip_update_E_post(fdtdhip_plan* plan, int64_t q);
+int fdtdhip_update_H_bulk(fdtdhip_plan* plan, int x0, int x1);
+int fdtdhip_update_H_post(fdtdhip_plan* plan, int64_t q);
+
+/* nsteps full steps starting at time index q0 (reference fdtd/grid.py:250-273). */
+int fdtdhip_run(fdtdhip_plan* plan, int64_t q0, int64_t nsteps);
+
+/* Kernel timing for benchmarks (the reference only has wall-clock timing around
+ * grid.run, examples/old/simulation_benchmark.py:96-107).  While enabled, every
+ * bulk kernel launch is bracketed by HIP events on the plan's stream.
+ * fdtdhip_plan_get_timing synchronises those events and returns, accumulated
+ * since the last call: total milliseconds and launch counts of the E and of the
+ * H bulk kernel. */
+int fdtdhip_plan_enable_timing(fdtdhip_plan* plan, int on);
+int fdtdhip_plan_get_timing(fdtdhip_plan* plan, double* ms_E, int64_t* launches_E,
+                            double* ms_H, int64_t* launches_H);
+
+/* Stand-alone curls (reference fdtd/grid.py:29-76): out = curl(in), both device
+ * (nx,ny,nz,3) arrays of `dtype`; enqueued on `stream`. */
+int fdtdhip_curl_E(const void* E, void* out, int nx, int ny, int nz, int dtype, void* stream);
+int fdtdhip_curl_H(const void* H, void* out, int nx, int ny, int nz, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDTD_HIP_H */
