@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <set>
 #include <string>
 #include <vector>
@@ -192,6 +193,47 @@ PmlK<T> make_pmlk(const fdtdhip_plan* p, const PmlH& h, bool phaseE) {
   return k;
 }
 
+// Kernel strategy, overridable for experiments with FDTDHIP_BULK, a '+'-separated
+// list of: generic (branchy one-lane-per-cell kernel), band (its XCD-banded
+// variant), flat | rows (lane mapping of the fast kernel), ntl / nts
+// (non-temporal loads of the streamed arrays / non-temporal stores), nont.
+// FDTDHIP_FORCE=1 applies the fast kernel to any grid size.
+struct Strategy {
+  bool chosen = false;  // FDTDHIP_BULK given: use it for every element type
+  bool fast = true;
+  bool flat = true;
+  bool ntl = true, nts = true;
+  bool band = false;
+  bool force = false;
+};
+
+const Strategy& strategy() {
+  static const Strategy st = [] {
+    Strategy s;
+    if (const char* e = getenv("FDTDHIP_BULK")) {
+      std::string v(e);
+      s.chosen = true;
+      v += "+";
+      size_t pos = 0, nxt;
+      while ((nxt = v.find('+', pos)) != std::string::npos) {
+        const std::string t = v.substr(pos, nxt - pos);
+        pos = nxt + 1;
+        if (t == "generic") s.fast = false;
+        else if (t == "band") { s.fast = false; s.band = true; }
+        else if (t == "flat") s.flat = true;
+        else if (t == "rows") s.flat = false;
+        else if (t == "nont") s.ntl = s.nts = false;
+        else if (t == "ntl") { s.ntl = true; s.nts = false; }
+        else if (t == "nts") { s.nts = true; s.ntl = false; }
+        else if (t == "nt") s.ntl = s.nts = true;
+      }
+    }
+    if (const char* e = getenv("FDTDHIP_FORCE")) s.force = atoi(e) != 0;
+    return s;
+  }();
+  return st;
+}
+
 int drain_timing(fdtdhip_plan* p) {
   for (size_t i = 0; i < p->ev_phase.size(); ++i) {
     float ms = 0;
@@ -245,20 +287,62 @@ int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
   a.obj = (const ObjK<T>*)p->obj_table;
   for (int i = 0; i < a.npml; ++i) a.pml[i] = make_pmlk<T>(p, p->pmls[i], phaseE);
 
-  if (tiled_applicable<T>(a)) return launch_tiled<T>(a, phaseE, p->stream) ? fail(-2, "tiled launch failed") : 0;
-
-  const int64_t ncell = (int64_t)(x1 - x0) * p->ny * p->nz;
-  const dim3 grid(blocks_for(ncell)), block(256);
   const bool pml = a.npml > 0, obj = a.nobj > 0;
-  if (phaseE) {
-    if (pml && obj) hipLaunchKernelGGL((bulk_E_generic<T, true, true>), grid, block, 0, p->stream, a);
-    else if (pml) hipLaunchKernelGGL((bulk_E_generic<T, true, false>), grid, block, 0, p->stream, a);
-    else if (obj) hipLaunchKernelGGL((bulk_E_generic<T, false, true>), grid, block, 0, p->stream, a);
-    else hipLaunchKernelGGL((bulk_E_generic<T, false, false>), grid, block, 0, p->stream, a);
-  } else {
-    if (pml) hipLaunchKernelGGL((bulk_H_generic<T, true>), grid, block, 0, p->stream, a);
-    else hipLaunchKernelGGL((bulk_H_generic<T, false>), grid, block, 0, p->stream, a);
+  const int64_t plane = (int64_t)p->ny * p->nz;
+  const Strategy st = strategy();
+  const dim3 block(256);
+
+  // Measured on MI355X (512^3 and 256^3, tools/kbench): float32 runs fastest with the
+  // unconditional-load kernel, flat lane mapping and non-temporal access to the
+  // streamed arrays (5.8 TB/s algorithmic, the rate of a plain 3-read-1-write
+  // stream); float64 cells are 24 B, every load splits in a 16 B and an 8 B
+  // instruction that touch the same lines, non-temporal lines are dropped between
+  // the two, and the one-lane-per-cell kernel with plain loads is fastest.
+  const bool fast = st.chosen ? st.fast : sizeof(T) == 4;
+  if (fast && (st.force || plane >= 4096) && (x1 - x0) <= 65535 && plane < (1ll << 30)) {
+    // flat: 256 consecutive cells per workgroup; rows: a wave per z-row segment
+    const bool flat = st.flat || p->nz < 48;
+    const dim3 grid = flat ? dim3((unsigned)((plane + 255) / 256), x1 - x0, 1)
+                           : dim3((p->nz + 63) / 64, (p->ny + 3) / 4, x1 - x0);
+    if (!flat && grid.y > 65535) return fail(-1, "grid too tall for the row kernel");
+#define FAST(FLAT, NT, NTS)                                                                         \
+  if (phaseE) {                                                                                     \
+    if (pml && obj) hipLaunchKernelGGL((bulk_E_rows<T, true, true, FLAT, NT, NTS>), grid, block, 0, p->stream, a);   \
+    else if (pml) hipLaunchKernelGGL((bulk_E_rows<T, true, false, FLAT, NT, NTS>), grid, block, 0, p->stream, a);    \
+    else if (obj) hipLaunchKernelGGL((bulk_E_rows<T, false, true, FLAT, NT, NTS>), grid, block, 0, p->stream, a);    \
+    else hipLaunchKernelGGL((bulk_E_rows<T, false, false, FLAT, NT, NTS>), grid, block, 0, p->stream, a);            \
+  } else {                                                                                          \
+    if (pml) hipLaunchKernelGGL((bulk_H_rows<T, true, FLAT, NT, NTS>), grid, block, 0, p->stream, a);  \
+    else hipLaunchKernelGGL((bulk_H_rows<T, false, FLAT, NT, NTS>), grid, block, 0, p->stream, a);     \
   }
+#define FAST2(FLAT)                                                     \
+  if (st.ntl && st.nts) { FAST(FLAT, true, true) }                      \
+  else if (st.ntl) { FAST(FLAT, true, false) }                          \
+  else if (st.nts) { FAST(FLAT, false, true) }                          \
+  else { FAST(FLAT, false, false) }
+    if (flat) { FAST2(true) } else { FAST2(false) }
+#undef FAST2
+#undef FAST
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+
+  const int64_t ncell = (int64_t)(x1 - x0) * plane;
+  const dim3 grid(blocks_for(ncell));
+  // XCD banding needs whole 256-cell blocks per plane, a multiple of 8 of them
+  const bool band = st.band && (plane % 2048 == 0);
+#define GENERIC(BAND)                                                                               \
+  if (phaseE) {                                                                                     \
+    if (pml && obj) hipLaunchKernelGGL((bulk_E_generic<T, true, true, BAND>), grid, block, 0, p->stream, a);  \
+    else if (pml) hipLaunchKernelGGL((bulk_E_generic<T, true, false, BAND>), grid, block, 0, p->stream, a);   \
+    else if (obj) hipLaunchKernelGGL((bulk_E_generic<T, false, true, BAND>), grid, block, 0, p->stream, a);   \
+    else hipLaunchKernelGGL((bulk_E_generic<T, false, false, BAND>), grid, block, 0, p->stream, a);           \
+  } else {                                                                                          \
+    if (pml) hipLaunchKernelGGL((bulk_H_generic<T, true, BAND>), grid, block, 0, p->stream, a);     \
+    else hipLaunchKernelGGL((bulk_H_generic<T, false, BAND>), grid, block, 0, p->stream, a);        \
+  }
+  if (band) { GENERIC(true) } else { GENERIC(false) }
+#undef GENERIC
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -13,47 +13,83 @@
 
 namespace fdtdhip {
 
-template <typename T>
-__device__ __forceinline__ void pml_pick(int axis, T d_x_y, T d_x_z, T d_y_x, T d_y_z, T d_z_x,
-                                         T d_z_y, T& dFu, T& dFv) {
-  // d_a_w = difference of component w along axis a.  u=(axis+1)%3, v=(axis+2)%3.
-  if (axis == 0) { dFu = d_x_y; dFv = d_x_z; }
-  else if (axis == 1) { dFu = d_y_z; dFv = d_y_x; }
-  else { dFu = d_z_x; dFv = d_z_y; }
+// One PML face acting on one cell (reference fdtd/boundaries.py:398-476), with the
+// normal axis a compile-time constant so that the two transverse components
+// u=(AXIS+1)%3, v=(AXIS+2)%3 are static register indices.
+//   dFu, dFv : difference along AXIS of components u and v of the driving field
+//   first    : E half step -> true: accumulate where slab-local index >= 1
+//              H half step -> false: accumulate where slab-local index <= t-2
+//   sign     : +1 for E (E += ...), -1 for H (H -= ...)
+template <typename T, int AXIS>
+__device__ __forceinline__ void pml_face(const PmlK<T>& P, int nx, int i, int j, int k, T dFu,
+                                         T dFv, bool phaseE, T sc, T f[3], const T m[3]) {
+  constexpr int u = (AXIS + 1) % 3, v = (AXIS + 2) % 3;
+  const int coord = AXIS == 0 ? i : (AXIS == 1 ? j : k);
+  const int l = coord - P.lo;
+  if (l < 0 || l >= P.t) return;
+  const int li = AXIS == 0 ? l : i, lj = AXIS == 1 ? l : j, lk = AXIS == 2 ? l : k;
+  const int64_t s = ((int64_t)li * P.sy + lj) * P.sz + lk;
+  const int64_t slab = (int64_t)(AXIS == 0 ? P.t : nx) * P.sy * P.sz;
+  const T b = P.b[l], cc = P.c[l];
+  T p0 = P.psi[s] * b, p1 = P.psi[slab + s] * b;
+  if (phaseE ? (l >= 1) : (l <= P.t - 2)) { p0 += dFv * cc; p1 += dFu * cc; }
+  P.psi[s] = p0;
+  P.psi[slab + s] = p1;
+  if (P.fused) {
+    if (phaseE) {
+      f[u] += (sc * m[u]) * (-p0);
+      f[v] += (sc * m[v]) * p1;
+    } else {
+      f[u] -= (sc * m[u]) * (-p0);
+      f[v] -= (sc * m[v]) * p1;
+    }
+  }
 }
+
+template <typename T>
+struct Diffs;
+
+// All PML faces of the plan, in registration order.  The loop is unrolled over
+// the six possible slots so that the descriptors are read from the kernel
+// argument segment at fixed offsets (scalar loads, no private-memory copy).
+template <typename T, bool PHASE_E>
+__device__ __forceinline__ void pml_all(const BulkArgs<T>& a, int i, int j, int k,
+                                        const Diffs<T>& d, T f[3], const T m[3]);
 
 // ---------------------------------------------------------------------------
 // E half step: PML memory update (reference fdtd/boundaries.py:422-448),
 // curl_H (fdtd/grid.py:54-76), E += sc*inv_eps*curl (grid.py:283), objects
 // (fdtd/objects.py:116-126, 204-218, 251-266), PML correction (boundaries.py:398-408).
 // ---------------------------------------------------------------------------
+// Differences of the driving field around one cell, named d_<axis>_<component>.
+template <typename T>
+struct Diffs {
+  T x_y, x_z, y_x, y_z, z_x, z_y;  // d_<axis>_<component>
+};
+
+template <typename T, bool PHASE_E>
+__device__ __forceinline__ void pml_all(const BulkArgs<T>& a, int i, int j, int k,
+                                        const Diffs<T>& d, T f[3], const T m[3]) {
+#pragma unroll
+  for (int p = 0; p < MAX_PML; ++p) {
+    if (p >= a.npml) break;
+    const PmlK<T>& P = a.pml[p];
+    if (P.axis == 0) pml_face<T, 0>(P, a.nx, i, j, k, d.x_y, d.x_z, PHASE_E, a.sc, f, m);
+    else if (P.axis == 1) pml_face<T, 1>(P, a.nx, i, j, k, d.y_z, d.y_x, PHASE_E, a.sc, f, m);
+    else pml_face<T, 2>(P, a.nx, i, j, k, d.z_x, d.z_y, PHASE_E, a.sc, f, m);
+  }
+}
+
+// Everything of the E half step that follows the neighbour differences, for one
+// cell: curl, grid update, objects in registration order, PML memory update
+// and correction.  `e` holds the cell's E on entry and the new E on return.
 template <typename T, bool HAS_PML, bool HAS_OBJ>
-__global__ __launch_bounds__(256) void bulk_E_generic(BulkArgs<T> a) {
-  const int64_t plane = (int64_t)a.ny * a.nz;
-  const int64_t ncell = (int64_t)(a.x1 - a.x0) * plane;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= ncell) return;
-  const int i = a.x0 + (int)(tid / plane);
-  const int64_t r = tid % plane;
-  const int j = (int)(r / a.nz);
-  const int k = (int)(r % a.nz);
-  const int64_t sz = 3, sy = 3 * (int64_t)a.nz, sx = 3 * plane;
-  const int64_t c3 = ((int64_t)i * plane + r) * 3;
-
-  const T* __restrict__ G = a.G;
-  const T hx = G[c3], hy = G[c3 + 1], hz = G[c3 + 2];
-  T d_y_z = 0, d_y_x = 0, d_z_y = 0, d_z_x = 0, d_x_z = 0, d_x_y = 0;
-  if (j > 0) { d_y_z = hz - G[c3 - sy + 2]; d_y_x = hx - G[c3 - sy]; }
-  if (k > 0) { d_z_y = hy - G[c3 - sz + 1]; d_z_x = hx - G[c3 - sz]; }
-  if (i > 0) { d_x_z = hz - G[c3 - sx + 2]; d_x_y = hy - G[c3 - sx + 1]; }
-  else if (a.ghost) { d_x_z = hz - a.ghost[r * 3 + 2]; d_x_y = hy - a.ghost[r * 3 + 1]; }
+__device__ __forceinline__ void finish_E(const BulkArgs<T>& a, int i, int j, int k,
+                                         const Diffs<T>& d, T e[3], const T m[3]) {
   T cu[3];
-  cu[0] = d_y_z - d_z_y;
-  cu[1] = d_z_x - d_x_z;
-  cu[2] = d_x_y - d_y_x;
-
-  T e[3] = {a.F[c3], a.F[c3 + 1], a.F[c3 + 2]};
-  const T m[3] = {a.mat[c3], a.mat[c3 + 1], a.mat[c3 + 2]};
+  cu[0] = d.y_z - d.z_y;
+  cu[1] = d.z_x - d.x_z;
+  cu[2] = d.x_y - d.y_x;
 #pragma unroll
   for (int c = 0; c < 3; ++c) e[c] += (a.sc * m[c]) * cu[c];
 
@@ -86,29 +122,61 @@ __global__ __launch_bounds__(256) void bulk_E_generic(BulkArgs<T> a) {
     }
   }
 
-  if (HAS_PML) {
-    for (int p = 0; p < a.npml; ++p) {
-      const PmlK<T>& P = a.pml[p];
-      const int coord = P.axis == 0 ? i : (P.axis == 1 ? j : k);
-      const int l = coord - P.lo;
-      if (l < 0 || l >= P.t) continue;
-      const int li = P.axis == 0 ? l : i, lj = P.axis == 1 ? l : j, lk = P.axis == 2 ? l : k;
-      const int64_t s = ((int64_t)li * P.sy + lj) * P.sz + lk;
-      const int64_t slab = (int64_t)(P.axis == 0 ? P.t : a.nx) * P.sy * P.sz;
-      T dFu, dFv;
-      pml_pick<T>(P.axis, d_x_y, d_x_z, d_y_x, d_y_z, d_z_x, d_z_y, dFu, dFv);
-      const T b = P.b[l], cc = P.c[l];
-      T p0 = P.psi[s] * b, p1 = P.psi[slab + s] * b;
-      if (l >= 1) { p0 += dFv * cc; p1 += dFu * cc; }
-      P.psi[s] = p0;
-      P.psi[slab + s] = p1;
-      if (P.fused) {
-        const int u = (P.axis + 1) % 3, v = (P.axis + 2) % 3;
-        e[u] += (a.sc * m[u]) * (-p0);
-        e[v] += (a.sc * m[v]) * p1;
-      }
-    }
-  }
+  if (HAS_PML) pml_all<T, true>(a, i, j, k, d, e, m);
+}
+
+// Same for the H half step (no objects: reference fdtd/objects.py:128-134).
+template <typename T, bool HAS_PML>
+__device__ __forceinline__ void finish_H(const BulkArgs<T>& a, int i, int j, int k,
+                                         const Diffs<T>& d, T h[3], const T m[3]) {
+  T cu[3];
+  cu[0] = d.y_z - d.z_y;
+  cu[1] = d.z_x - d.x_z;
+  cu[2] = d.x_y - d.y_x;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) h[c] -= (a.sc * m[c]) * cu[c];
+
+  if (HAS_PML) pml_all<T, false>(a, i, j, k, d, h, m);
+}
+
+// Block index -> block of work.  With BAND, the 8 XCDs (blocks are dealt to them
+// round robin, so blocks b and b+8 share an L2) each take a contiguous band of
+// rows of every x plane: the y- and x-neighbours of a cell are then fetched by
+// the same XCD and hit its L2 instead of crossing the fabric again.  Purely a
+// speed matter: any mapping gives the same results.
+template <bool BAND>
+__device__ __forceinline__ int64_t work_block(int64_t blocks_per_plane) {
+  const int64_t b = blockIdx.x;
+  if (!BAND) return b;
+  const int64_t per = blocks_per_plane >> 3;
+  const int64_t xcd = b & 7, s = b >> 3;
+  return (s / per) * blocks_per_plane + xcd * per + (s % per);
+}
+
+template <typename T, bool HAS_PML, bool HAS_OBJ, bool BAND>
+__global__ __launch_bounds__(256) void bulk_E_generic(BulkArgs<T> a) {
+  const int64_t plane = (int64_t)a.ny * a.nz;
+  const int64_t ncell = (int64_t)(a.x1 - a.x0) * plane;
+  const int64_t tid = work_block<BAND>(plane >> 8) * blockDim.x + threadIdx.x;
+  if (tid >= ncell) return;
+  const int i = a.x0 + (int)(tid / plane);
+  const int64_t r = tid % plane;
+  const int j = (int)(r / a.nz);
+  const int k = (int)(r % a.nz);
+  const int64_t sz = 3, sy = 3 * (int64_t)a.nz, sx = 3 * plane;
+  const int64_t c3 = ((int64_t)i * plane + r) * 3;
+
+  const T* __restrict__ G = a.G;
+  const T hx = G[c3], hy = G[c3 + 1], hz = G[c3 + 2];
+  Diffs<T> d = {0, 0, 0, 0, 0, 0};
+  if (j > 0) { d.y_z = hz - G[c3 - sy + 2]; d.y_x = hx - G[c3 - sy]; }
+  if (k > 0) { d.z_y = hy - G[c3 - sz + 1]; d.z_x = hx - G[c3 - sz]; }
+  if (i > 0) { d.x_z = hz - G[c3 - sx + 2]; d.x_y = hy - G[c3 - sx + 1]; }
+  else if (a.ghost) { d.x_z = hz - a.ghost[r * 3 + 2]; d.x_y = hy - a.ghost[r * 3 + 1]; }
+
+  T e[3] = {a.F[c3], a.F[c3 + 1], a.F[c3 + 2]};
+  const T m[3] = {a.mat[c3], a.mat[c3 + 1], a.mat[c3 + 2]};
+  finish_E<T, HAS_PML, HAS_OBJ>(a, i, j, k, d, e, m);
   a.F[c3] = e[0];
   a.F[c3 + 1] = e[1];
   a.F[c3 + 2] = e[2];
@@ -120,11 +188,11 @@ __global__ __launch_bounds__(256) void bulk_E_generic(BulkArgs<T> a) {
 // correction (boundaries.py:410-420).  Objects do nothing in this half step
 // (fdtd/objects.py:128-134, 220-226, 268-274).
 // ---------------------------------------------------------------------------
-template <typename T, bool HAS_PML>
+template <typename T, bool HAS_PML, bool BAND>
 __global__ __launch_bounds__(256) void bulk_H_generic(BulkArgs<T> a) {
   const int64_t plane = (int64_t)a.ny * a.nz;
   const int64_t ncell = (int64_t)(a.x1 - a.x0) * plane;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t tid = work_block<BAND>(plane >> 8) * blockDim.x + threadIdx.x;
   if (tid >= ncell) return;
   const int i = a.x0 + (int)(tid / plane);
   const int64_t r = tid % plane;
@@ -135,44 +203,15 @@ __global__ __launch_bounds__(256) void bulk_H_generic(BulkArgs<T> a) {
 
   const T* __restrict__ G = a.G;
   const T ex = G[c3], ey = G[c3 + 1], ez = G[c3 + 2];
-  T d_y_z = 0, d_y_x = 0, d_z_y = 0, d_z_x = 0, d_x_z = 0, d_x_y = 0;
-  if (j < a.ny - 1) { d_y_z = G[c3 + sy + 2] - ez; d_y_x = G[c3 + sy] - ex; }
-  if (k < a.nz - 1) { d_z_y = G[c3 + sz + 1] - ey; d_z_x = G[c3 + sz] - ex; }
-  if (i < a.nx - 1) { d_x_z = G[c3 + sx + 2] - ez; d_x_y = G[c3 + sx + 1] - ey; }
-  else if (a.ghost) { d_x_z = a.ghost[r * 3 + 2] - ez; d_x_y = a.ghost[r * 3 + 1] - ey; }
-  T cu[3];
-  cu[0] = d_y_z - d_z_y;
-  cu[1] = d_z_x - d_x_z;
-  cu[2] = d_x_y - d_y_x;
+  Diffs<T> d = {0, 0, 0, 0, 0, 0};
+  if (j < a.ny - 1) { d.y_z = G[c3 + sy + 2] - ez; d.y_x = G[c3 + sy] - ex; }
+  if (k < a.nz - 1) { d.z_y = G[c3 + sz + 1] - ey; d.z_x = G[c3 + sz] - ex; }
+  if (i < a.nx - 1) { d.x_z = G[c3 + sx + 2] - ez; d.x_y = G[c3 + sx + 1] - ey; }
+  else if (a.ghost) { d.x_z = a.ghost[r * 3 + 2] - ez; d.x_y = a.ghost[r * 3 + 1] - ey; }
 
   T h[3] = {a.F[c3], a.F[c3 + 1], a.F[c3 + 2]};
   const T m[3] = {a.mat[c3], a.mat[c3 + 1], a.mat[c3 + 2]};
-#pragma unroll
-  for (int c = 0; c < 3; ++c) h[c] -= (a.sc * m[c]) * cu[c];
-
-  if (HAS_PML) {
-    for (int p = 0; p < a.npml; ++p) {
-      const PmlK<T>& P = a.pml[p];
-      const int coord = P.axis == 0 ? i : (P.axis == 1 ? j : k);
-      const int l = coord - P.lo;
-      if (l < 0 || l >= P.t) continue;
-      const int li = P.axis == 0 ? l : i, lj = P.axis == 1 ? l : j, lk = P.axis == 2 ? l : k;
-      const int64_t s = ((int64_t)li * P.sy + lj) * P.sz + lk;
-      const int64_t slab = (int64_t)(P.axis == 0 ? P.t : a.nx) * P.sy * P.sz;
-      T dFu, dFv;
-      pml_pick<T>(P.axis, d_x_y, d_x_z, d_y_x, d_y_z, d_z_x, d_z_y, dFu, dFv);
-      const T b = P.b[l], cc = P.c[l];
-      T p0 = P.psi[s] * b, p1 = P.psi[slab + s] * b;
-      if (l <= P.t - 2) { p0 += dFv * cc; p1 += dFu * cc; }
-      P.psi[s] = p0;
-      P.psi[slab + s] = p1;
-      if (P.fused) {
-        const int u = (P.axis + 1) % 3, v = (P.axis + 2) % 3;
-        h[u] -= (a.sc * m[u]) * (-p0);
-        h[v] -= (a.sc * m[v]) * p1;
-      }
-    }
-  }
+  finish_H<T, HAS_PML>(a, i, j, k, d, h, m);
   a.F[c3] = h[0];
   a.F[c3 + 1] = h[1];
   a.F[c3 + 2] = h[2];

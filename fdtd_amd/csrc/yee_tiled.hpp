@@ -1,7 +1,132 @@
-// Tuned large-grid kernels (x-marching tiles).  Placeholder: nothing applies yet.
+// Large-grid Yee half-step kernels: one lane per cell, a wavefront per z-row
+// segment.
+//
+// Workgroup = 256 lanes = 4 wavefronts; wavefront w handles 64 adjacent cells of
+// row j = 4*blockIdx.y + w, plane i = x0 + blockIdx.z, starting at z = 64*blockIdx.x.
+// A wave therefore reads 64 adjacent cells (768 contiguous bytes in float32) with
+// every load, and i, j are wave-uniform (scalar registers, no index division).
+//
+// All loads of a lane are unconditional and issued back to back -- at a domain
+// edge the neighbour address is clamped to the cell itself and the difference is
+// discarded -- so the wave waits once for memory instead of once per neighbour.
+// Neighbour re-reads (row j-1, plane i-1, cell k-1) are served by L1/L2/Infinity
+// Cache; HBM sees each array once per half step.
+// Per-cell arithmetic is shared with the shape-agnostic kernels (finish_E/H).
 #pragma once
+
 #include "plan.hpp"
+#include "yee_generic.hpp"
+
 namespace fdtdhip {
-template <typename T> inline bool tiled_applicable(const BulkArgs<T>&) { return false; }
-template <typename T> inline int launch_tiled(const BulkArgs<T>&, bool, hipStream_t) { return -1; }
+
+template <typename T, bool NT>
+__device__ __forceinline__ void load3(const T* p, T& x, T& y, T& z) {
+  if (NT) {
+    x = __builtin_nontemporal_load(p);
+    y = __builtin_nontemporal_load(p + 1);
+    z = __builtin_nontemporal_load(p + 2);
+  } else {
+    x = p[0]; y = p[1]; z = p[2];
+  }
+}
+
+template <typename T, bool NT>
+__device__ __forceinline__ void store3(T* p, T x, T y, T z) {
+  if (NT) {
+    __builtin_nontemporal_store(x, p);
+    __builtin_nontemporal_store(y, p + 1);
+    __builtin_nontemporal_store(z, p + 2);
+  } else {
+    p[0] = x; p[1] = y; p[2] = z;
+  }
+}
+
+// Cell of this lane.  FLAT: 256 consecutive cells of the flattened (y, z) plane per
+// workgroup (grid = blocks per plane x planes); otherwise a wave per z-row segment
+// (grid = z tiles x row quads x planes).
+template <bool FLAT>
+__device__ __forceinline__ bool lane_cell(int x0, int ny, int nz, int& i, int& j, int& k) {
+  if (FLAT) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    i = x0 + blockIdx.y;
+    j = r / nz;
+    k = r - j * nz;
+    return j < ny;
+  }
+  k = blockIdx.x * 64 + (threadIdx.x & 63);
+  j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  i = x0 + blockIdx.z;
+  return k < nz && j < ny;
+}
+
+template <typename T, bool HAS_PML, bool HAS_OBJ, bool FLAT, bool NT, bool NTS>
+__global__ __launch_bounds__(256) void bulk_E_rows(BulkArgs<T> a) {
+  int i, j, k;
+  if (!lane_cell<FLAT>(a.x0, a.ny, a.nz, i, j, k)) return;
+  const int64_t sy = 3 * (int64_t)a.nz, sx = sy * a.ny;
+  const int64_t r3 = (int64_t)j * sy + 3 * k;
+  const int64_t c3 = (int64_t)i * sx + r3;
+  const T* __restrict__ g = a.G + c3;
+
+  const bool hasx = i > 0 || a.ghost != nullptr, hasy = j > 0, hasz = k > 0;
+  const T* gx = i > 0 ? g - sx : (a.ghost ? a.ghost + r3 : g);
+  const T* gy = hasy ? g - sy : g;
+  const T* gz = hasz ? g - 3 : g;
+
+  T hx, hy, hz, xx, xy, xz, yx, yy, yz, zx, zy, zz_;
+  load3<T, false>(g, hx, hy, hz);
+  load3<T, false>(gx, xx, xy, xz);
+  load3<T, false>(gy, yx, yy, yz);
+  load3<T, false>(gz, zx, zy, zz_);
+  T e[3], m[3];
+  load3<T, NT>(a.F + c3, e[0], e[1], e[2]);
+  load3<T, NT>(a.mat + c3, m[0], m[1], m[2]);
+  (void)xx; (void)yy; (void)zz_;
+
+  Diffs<T> d;
+  d.x_y = hasx ? hy - xy : T(0);
+  d.x_z = hasx ? hz - xz : T(0);
+  d.y_x = hasy ? hx - yx : T(0);
+  d.y_z = hasy ? hz - yz : T(0);
+  d.z_x = hasz ? hx - zx : T(0);
+  d.z_y = hasz ? hy - zy : T(0);
+  finish_E<T, HAS_PML, HAS_OBJ>(a, i, j, k, d, e, m);
+  store3<T, NTS>(a.F + c3, e[0], e[1], e[2]);
+}
+
+template <typename T, bool HAS_PML, bool FLAT, bool NT, bool NTS>
+__global__ __launch_bounds__(256) void bulk_H_rows(BulkArgs<T> a) {
+  int i, j, k;
+  if (!lane_cell<FLAT>(a.x0, a.ny, a.nz, i, j, k)) return;
+  const int64_t sy = 3 * (int64_t)a.nz, sx = sy * a.ny;
+  const int64_t r3 = (int64_t)j * sy + 3 * k;
+  const int64_t c3 = (int64_t)i * sx + r3;
+  const T* __restrict__ g = a.G + c3;
+
+  const bool hasx = i < a.nx - 1 || a.ghost != nullptr, hasy = j < a.ny - 1, hasz = k < a.nz - 1;
+  const T* gx = i < a.nx - 1 ? g + sx : (a.ghost ? a.ghost + r3 : g);
+  const T* gy = hasy ? g + sy : g;
+  const T* gz = hasz ? g + 3 : g;
+
+  T ex, ey, ez, xx, xy, xz, yx, yy, yz, zx, zy, zz_;
+  load3<T, false>(g, ex, ey, ez);
+  load3<T, false>(gx, xx, xy, xz);
+  load3<T, false>(gy, yx, yy, yz);
+  load3<T, false>(gz, zx, zy, zz_);
+  T h[3], m[3];
+  load3<T, NT>(a.F + c3, h[0], h[1], h[2]);
+  load3<T, NT>(a.mat + c3, m[0], m[1], m[2]);
+  (void)xx; (void)yy; (void)zz_;
+
+  Diffs<T> d;
+  d.x_y = hasx ? xy - ey : T(0);
+  d.x_z = hasx ? xz - ez : T(0);
+  d.y_x = hasy ? yx - ex : T(0);
+  d.y_z = hasy ? yz - ez : T(0);
+  d.z_x = hasz ? zx - ex : T(0);
+  d.z_y = hasz ? zy - ey : T(0);
+  finish_H<T, HAS_PML>(a, i, j, k, d, h, m);
+  store3<T, NTS>(a.F + c3, h[0], h[1], h[2]);
+}
+
 }  // namespace fdtdhip
