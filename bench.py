@@ -98,6 +98,11 @@ def build_workload(fdtd, name, n_slabs=1, rank=0):
         grid[:, 0:10, :] = fdtd.PML()
         grid[:, -10:, :] = fdtd.PML()
         desc += " README example"
+    if name != "c1":
+        # non-trivial data everywhere (all-zero fields would flatter power and clocks)
+        gen = torch.Generator(device=grid.E.device).manual_seed(1234 + rank)
+        for f in (grid.E, grid.H):
+            f.uniform_(-1e-3, 1e-3, generator=gen)
     cells = shape[0] * shape[1] * shape[2]
     # bulk traffic per cell and step: each half step reads 9 values, writes 3
     return grid, cells, 24 * es, dt, desc

@@ -1,0 +1,16 @@
+#!/bin/bash
+# rocprofv3 kernel trace + stats of the default bench command; summary copied to profiles/.
+# usage: tools/profile_bench.sh <tag> [bench args]
+set -e
+cd "$(dirname "$0")/.."
+tag=$1; shift
+export TMPDIR=/tmp
+out=gpurun_out/prof_$tag
+rm -rf "$out"; mkdir -p "$out"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 bench.py --no-cpu-baseline "$@" > "$out/bench.log" 2>&1
+tail -1 "$out/bench.log"
+f=$(find "$out" -name "*kernel_stats.csv" | head -1)
+mkdir -p gpurun_out/profiles_$tag
+cp "$f" gpurun_out/profiles_$tag/kernel_stats.csv
+tail -1 "$out/bench.log" > gpurun_out/profiles_$tag/bench_line.json
+head -8 "$f"
