@@ -57,7 +57,7 @@ def build_workload(fdtd, name, n_slabs=1, rank=0):
         grid = SlabGrid((shape[0] * n_slabs, shape[1], shape[2]))
     else:
         grid = fdtd.Grid(shape)
-    nx, ny, nz = grid.Nx, grid.Ny, grid.Nz  # global extents
+    nx, ny, nz = grid.Nx_global, grid.Ny, grid.Nz  # extents of the whole simulation
     desc = f"{nx}x{ny}x{nz} {dt}"
     if name == "m3v":
         grid[nx // 2, ny // 2, nz // 2] = fdtd.PointSource(period=20)
@@ -158,11 +158,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; FDTD_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals
+    backend = os.environ.get("FDTD_DIST_BACKEND", "nccl")
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     import fdtd_amd as fdtd
     from fdtd_amd import _lib
@@ -197,8 +203,12 @@ def main():
         total_cells = cells * world
         value = total_cells * args.steps / elapsed / 1e9
         # dominant kernel: the bulk half-step kernel (E and H variants move the same bytes)
+        # One half step of one GPU = `cells` cells = one bulk launch on a single GPU; on a
+        # slab it is two launches (interior planes, then the plane that waits for the
+        # halo), so durations are summed per half step before dividing.
         launches = nE.value + nH.value
-        avg_ms = (msE.value + msH.value) / max(launches, 1)
+        half_steps = 2 * args.steps
+        avg_ms = (msE.value + msH.value) / half_steps
         bytes_per_launch = cells * bytes_per_cell / 2
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
@@ -221,8 +231,8 @@ def main():
                 "kernel": "bulk half-step kernel (E and H)",
                 "bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": round(avg_ms, 4),
-                "avg_launch_ms_E": round(msE.value / max(nE.value, 1), 4),
-                "avg_launch_ms_H": round(msH.value / max(nH.value, 1), 4),
+                "avg_launch_ms_E": round(msE.value / args.steps, 4),
+                "avg_launch_ms_H": round(msH.value / args.steps, 4),
                 "launches": launches,
             },
         }

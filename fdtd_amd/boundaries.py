@@ -98,6 +98,11 @@ class PeriodicBoundary(Boundary):
                 if taken:
                     grid.boundaries.remove(self)
                     raise AttributeError(f"grid already has an {letter}low/{letter}high boundary!")
+                if axis == 0 and grid.Nx != grid.Nx_global:
+                    grid.boundaries.remove(self)
+                    raise NotImplementedError(
+                        "a periodic boundary along x is not available on an x-slab "
+                        "decomposed grid")
                 for a in attrs:
                     setattr(grid, a, self)
                 self.__class__ = _PERIODIC_CLASSES[axis]
@@ -183,8 +188,13 @@ class PML(Boundary):
         t = self.thickness = int(thickness)
         g = self.grid
         n = g.shape[self.axis]
+        # an x-face PML exists only on the slab that holds that face of the simulation
+        self._active = self.axis != 0 or (g._is_first_slab if self.side == "low" else g._is_last_slab)
+        if not self._active:
+            self._psiE = self._psiH = None
+            return
         if t > n:
-            raise IndexError("PML thicker than the grid")
+            raise IndexError("PML thicker than the grid (or than the x-slab that holds it)")
         span = slice(None, t) if self.side == "low" else slice(-t, None)
         loc = [slice(None)] * 3
         loc[self.axis] = span
@@ -213,10 +223,14 @@ class PML(Boundary):
         self._psiH = bd.zeros((2,) + self.shape)
 
     def _signature(self):
+        if not self._active:
+            return ("pml-elsewhere", id(self))
         return ("pml", id(self), self.axis, self.side, self.thickness,
                 self._psiE.data_ptr(), self._psiH.data_ptr(), self._psiE.dtype)
 
     def _native_add(self, lib, plan):
+        if not self._active:
+            return
         for name in ("_psiE", "_psiH"):
             t = getattr(self, name)
             if t.dtype != bd.float or t.device != bd.device or not t.is_contiguous():

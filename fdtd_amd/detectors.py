@@ -67,16 +67,24 @@ class _Detector:
     def _points(self):
         raise NotImplementedError
 
-    def _native_add(self, lib, plan):
+    def _local_points(self):
+        """Points of this detector that lie in this grid's x planes, in local coordinates
+        (all of them unless the grid is one x-slab of a decomposed simulation)."""
         g = self.grid
-        flat = []
+        out = []
         for x, y, z in self._points():
-            for v, n in ((x, g.Nx), (y, g.Ny), (z, g.Nz)):
+            for v, n in ((x, g.Nx_global), (y, g.Ny), (z, g.Nz)):
                 if not -n <= v < n:
                     raise IndexError(f"index {v} is out of bounds for axis with size {n}")
-                flat.append(v % n)
+            xl = g._local_x(x % g.Nx_global)
+            if xl is not None:
+                out.append((xl, y % g.Ny, z % g.Nz))
+        return out
+
+    def _native_add(self, lib, plan):
+        flat = [v for p in self._local_points() for v in p]
         self._id = _lib.check(lib.fdtdhip_plan_add_detector(
-            plan, self._kind, len(flat) // 3, _lib.int32s(flat), g.grid_spacing))
+            plan, self._kind, len(flat) // 3, _lib.int32s(flat), self.grid.grid_spacing))
 
     def detect_E(self):
         pass
@@ -110,7 +118,7 @@ class LineDetector(_Detector):
         return list(zip(self.x, self.y, self.z))
 
     def _shape(self):
-        return (len(self.x), 3)
+        return (len(self._local_points()), 3)
 
     def _reserve(self, lib, plan, nE, nH):
         if self._bufE is None:
@@ -136,7 +144,7 @@ def _block_lists(grid, x, y, z):
             )
         return x, y, z
     out = []
-    for key, n in ((x, grid.Nx), (y, grid.Ny), (z, grid.Nz)):
+    for key, n in ((x, grid.Nx_global), (y, grid.Ny), (z, grid.Nz)):
         if isinstance(key, list):
             key = slice(key[0], key[-1], None)
         a = key.start if key.start is not None else 0
@@ -155,8 +163,12 @@ class BlockDetector(LineDetector):
     def _points(self):
         return [(i, j, k) for i in self.x for j in self.y for k in self.z]
 
+    def _local_x_count(self):
+        g = self.grid
+        return sum(1 for x in self.x if g._local_x(x % g.Nx_global) is not None)
+
     def _shape(self):
-        return (len(self.x), len(self.y), len(self.z), 3)
+        return (self._local_x_count(), len(self.y), len(self.z), 3)
 
 
 class CurrentDetector(_Detector):
@@ -178,7 +190,9 @@ class CurrentDetector(_Detector):
 
     def _reserve(self, lib, plan, nE, nH):
         if self._bufH is None:
-            self._bufH = _Readings((len(self.x), len(self.y), len(self.z)))
+            g = self.grid
+            nxl = sum(1 for x in self.x if g._local_x(x % g.Nx_global) is not None)
+            self._bufH = _Readings((nxl, len(self.y), len(self.z)))
         pH = self._bufH.reserve(nH)
         _lib.check(lib.fdtdhip_plan_set_detector_output(
             plan, self._id, None, ctypes.c_void_p(pH), nH))

@@ -70,6 +70,10 @@ class Grid:
         self.grid_spacing = float(grid_spacing)
         self.Nx, self.Ny, self.Nz = self._handle_tuple(shape)
         self.D = int(self.Nx > 1) + int(self.Ny > 1) + int(self.Nz > 1)
+        # extent of the whole simulation along x and where this grid's planes start in it;
+        # a plain Grid is the whole simulation, an x-slab (fdtd_amd.parallel.SlabGrid) a part
+        self.Nx_global, self.x_offset = self.Nx, 0
+        self._partition()
 
         limit = float(self.D) ** (-0.5)
         if courant_number is None:
@@ -98,6 +102,35 @@ class Grid:
         self._plan = None
         self._plan_signature = None
         self._halo = (None, None)  # (H plane below, E plane above) of an x-slab
+
+    # ----------------------------------------------------------- x-slab hooks
+    def _partition(self):
+        """Choose this grid's share of the x planes (whole range for a plain Grid)."""
+
+    def _clip_x(self, start, stop):
+        """Global plane range [start, stop) -> local range (lo, hi); hi <= lo if none is local."""
+        lo = max(start - self.x_offset, 0)
+        hi = min(stop - self.x_offset, self.Nx)
+        return lo, max(lo, hi)
+
+    def _local_x(self, xg):
+        """Global plane index -> local index, or None if another slab owns it."""
+        xl = xg - self.x_offset
+        return xl if 0 <= xl < self.Nx else None
+
+    @property
+    def _is_first_slab(self):
+        return self.x_offset == 0
+
+    @property
+    def _is_last_slab(self):
+        return self.x_offset + self.Nx == self.Nx_global
+
+    def _border_inv_eps_x(self, y, z):
+        """Component 0 of the inverse permittivity on the LAST x plane of the whole
+        simulation over the (y, z) window: what objects copy onto their far x face
+        (reference fdtd/objects.py:77-80)."""
+        return self.inverse_permittivity[-1, y, z, 0]
 
     @staticmethod
     def _material(value):

@@ -33,12 +33,17 @@ class Object:
         self.grid = grid
         grid.objects.append(self)
         grid._claim_name(self)
-        self.x = self._handle_slice(x, max_index=grid.Nx)
+        # x in the coordinates of the whole simulation, then the part this grid owns
+        # (everything, unless the grid is one x-slab of a decomposed simulation)
+        self.x_global = self._handle_slice(x, max_index=grid.Nx_global)
+        lo, hi = grid._clip_x(self.x_global.start, self.x_global.stop)
+        self.x = slice(lo, hi, None)
         self.y = self._handle_slice(y, max_index=grid.Ny)
         self.z = self._handle_slice(z, max_index=grid.Nz)
         self.Nx = abs(self.x.stop - self.x.start)
         self.Ny = abs(self.y.stop - self.y.start)
         self.Nz = abs(self.z.stop - self.z.start)
+        whole_Nx = abs(self.x_global.stop - self.x_global.start)
 
         perm = self.permittivity
         if bd.is_array(perm):
@@ -46,12 +51,17 @@ class Object:
             if perm.dim() == 3:
                 perm = perm[:, :, :, None]
             self.permittivity = perm
+            if perm.dim() == 4 and perm.shape[0] == whole_Nx and whole_Nx != self.Nx:
+                first = lo + grid.x_offset - self.x_global.start
+                perm = perm[first:first + self.Nx]
         inv = bd.ones((self.Nx, self.Ny, self.Nz, 3)) / perm
 
         # far faces take the grid's border value so that the object is symmetric
         gi = grid.inverse_permittivity
-        if self.Nx > 1:
-            inv[-1, :, :, 0] = gi[-1, self.y, self.z, 0]
+        border_x = grid._border_inv_eps_x(self.y, self.z)  # collective on a decomposed grid
+        owns_far_x = self.Nx > 0 and grid.x_offset + hi == self.x_global.stop
+        if whole_Nx > 1 and owns_far_x:
+            inv[-1, :, :, 0] = border_x
         if self.Ny > 1:
             inv[:, -1, :, 1] = gi[self.x, -1, self.z, 1]
         if self.Nz > 1:
@@ -104,6 +114,8 @@ class Object:
                 self._tensor("inverse_permittivity").data_ptr())
 
     def _native_add(self, lib, plan):
+        if self.Nx == 0:  # no cell of the box lies in this x-slab
+            return
         _lib.check(lib.fdtdhip_plan_add_object(
             plan, self._native_kind, _lib.int32s(self._box()),
             ctypes.c_void_p(self._tensor("inverse_permittivity").data_ptr()), None))
@@ -144,6 +156,8 @@ class AbsorbingObject(Object):
         return super()._signature() + (self._tensor("absorption_factor").data_ptr(),)
 
     def _native_add(self, lib, plan):
+        if self.Nx == 0:
+            return
         _lib.check(lib.fdtdhip_plan_add_object(
             plan, self._native_kind, _lib.int32s(self._box()),
             ctypes.c_void_p(self._tensor("inverse_permittivity").data_ptr()),

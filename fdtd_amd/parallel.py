@@ -1,0 +1,221 @@
+"""Multi-GPU runs: x-slab domain decomposition, one process per GPU.
+
+The reference is single device (no counterpart).  What decomposes: along x,
+``update_E`` at plane i needs Hy, Hz of plane i-1 (reference fdtd/grid.py:71,73) and
+``update_H`` at plane i needs Ey, Ez of plane i+1 (fdtd/grid.py:46,48); nothing else
+crosses an x face.  So every rank owns a contiguous range of x planes of all four
+field arrays and, per half step, receives ONE plane from one neighbour:
+
+    before update_E : last H plane of rank r-1  ->  ``H_below`` of rank r
+    before update_H : first E plane of rank r+1 ->  ``E_above`` of rank r
+
+A plane of the ``(Nx, Ny, Nz, 3)`` layout is one contiguous block, so planes are sent
+straight out of the field arrays and received into two small ghost buffers that
+the kernels read in place of the domain-edge mask (``fdtdhip_plan_set_halo``).
+
+Overlap: the exchange is started first, the interior planes (which do not need the
+ghost) are enqueued on the compute stream, then the stream waits for the exchange
+and the one boundary plane is computed.  With the RCCL backend the transfer runs on
+RCCL's own stream over xGMI while the interior kernel runs.
+
+``SlabGrid`` takes keys in the coordinates of the WHOLE simulation
+(``grid[x, y, z] = thing`` as for a plain ``Grid``, executed on every rank); each
+component keeps only the part that lies in the rank's planes.
+"""
+
+import ctypes
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .backend import backend as bd
+from .grid import Grid
+
+
+class _NativeEngine:
+    """Half-step pieces of one slab executed by libfdtd_hip."""
+
+    def __init__(self, grid):
+        self.grid = grid
+
+    def prepare(self):
+        self.lib = self.grid._ensure_plan()
+        self.plan = self.grid._plan
+
+    def reserve_detectors(self, nE, nH):
+        for det in self.grid.detectors:
+            det._reserve(self.lib, self.plan, nE, nH)
+
+    def commit_detectors(self, nE, nH):
+        for det in self.grid.detectors:
+            det._commit(nE, nH)
+
+    def bulk_E(self, x0, x1):
+        _lib.check(self.lib.fdtdhip_update_E_bulk(self.plan, x0, x1))
+
+    def post_E(self, q):
+        _lib.check(self.lib.fdtdhip_update_E_post(self.plan, q))
+
+    def bulk_H(self, x0, x1):
+        _lib.check(self.lib.fdtdhip_update_H_bulk(self.plan, x0, x1))
+
+    def post_H(self, q):
+        _lib.check(self.lib.fdtdhip_update_H_post(self.plan, q))
+
+
+class _Exchange:
+    """One in-flight neighbour exchange (send one plane, receive one plane)."""
+
+    def __init__(self, works, staged=None):
+        self.works, self.staged = works, staged
+
+    def wait(self):
+        for w in self.works:
+            w.wait()  # RCCL: makes the current stream wait; gloo: blocks the host
+        if self.staged is not None:
+            host, device = self.staged
+            device.copy_(host)
+
+
+class SlabGrid(Grid):
+    """One x-slab of a decomposed simulation.  ``shape`` is the shape of the whole
+    simulation; planes are dealt to the ranks of ``group`` in rank order, as evenly
+    as possible.  Requires an initialised ``torch.distributed`` process group
+    ("nccl", i.e. RCCL, for GPUs)."""
+
+    def __init__(self, shape, grid_spacing=155e-9, permittivity=1.0, permeability=1.0,
+                 courant_number=None, group=None, engine_factory=None):
+        if not dist.is_initialized():
+            raise RuntimeError("SlabGrid needs torch.distributed.init_process_group first")
+        self._group = group
+        self._rank = dist.get_rank(group)
+        self._world = dist.get_world_size(group)
+        self._backend_name = dist.get_backend(group)
+        super().__init__(shape, grid_spacing, permittivity, permeability, courant_number)
+        plane = (self.Ny, self.Nz, 3)
+        self._H_below = bd.zeros(plane) if self._rank > 0 else None
+        self._E_above = bd.zeros(plane) if self._rank < self._world - 1 else None
+        self._halo = (self._H_below, self._E_above)
+        self._engine = (engine_factory or _NativeEngine)(self)
+
+    # ------------------------------------------------------------ decomposition
+    def _partition(self):
+        n, p, r = self.Nx_global, self._world, self._rank
+        if n < p:
+            raise ValueError(f"cannot split {n} x planes over {p} ranks")
+        base, extra = divmod(n, p)
+        self.Nx = base + (1 if r < extra else 0)
+        self.x_offset = r * base + min(r, extra)
+
+    def _global_rank(self, r):
+        return r if self._group is None else dist.get_global_rank(self._group, r)
+
+    def _border_inv_eps_x(self, y, z):
+        """Collective: every rank gets the last rank's ``inverse_permittivity[-1, y, z, 0]``."""
+        shape = self.inverse_permittivity[-1, y, z, 0].shape
+        last = self._world - 1
+        if self._rank == last:
+            buf = self.inverse_permittivity[-1, y, z, 0].clone().contiguous()
+        else:
+            buf = bd.zeros(tuple(shape))
+        if self._backend_name != "nccl" and buf.is_cuda:
+            host = buf.cpu()
+            dist.broadcast(host, src=self._global_rank(last), group=self._group)
+            buf.copy_(host)
+        else:
+            dist.broadcast(buf, src=self._global_rank(last), group=self._group)
+        return buf
+
+    # ------------------------------------------------------------ halo exchange
+    def _start_exchange(self, send, dst, recv, src):
+        """Send plane ``send`` to rank ``dst`` and receive into ``recv`` from rank ``src``
+        (either may be None at the ends of the chain)."""
+        if send is None and recv is None:
+            return None
+        staged = None
+        if self._backend_name != "nccl" and (send if send is not None else recv).is_cuda:
+            # transports without device-memory support (gloo): stage through the host
+            if send is not None:
+                send = send.cpu()
+            if recv is not None:
+                staged = (torch.empty(recv.shape, dtype=recv.dtype), recv)
+                recv = staged[0]
+        ops = []
+        if send is not None:
+            ops.append(dist.P2POp(dist.isend, send, self._global_rank(dst), self._group))
+        if recv is not None:
+            ops.append(dist.P2POp(dist.irecv, recv, self._global_rank(src), self._group))
+        return _Exchange(dist.batch_isend_irecv(ops), staged)
+
+    # ----------------------------------------------------------------- stepping
+    def _half_step_E(self, eng, q):
+        r, p = self._rank, self._world
+        ex = self._start_exchange(self.H[-1] if r < p - 1 else None, r + 1,
+                                  self._H_below, r - 1)
+        first = 1 if r > 0 else 0
+        eng.bulk_E(first, self.Nx)       # planes that do not need the ghost plane
+        if ex is not None:
+            ex.wait()
+        if first:
+            eng.bulk_E(0, 1)             # the plane that reads H_below
+        eng.post_E(q)
+
+    def _half_step_H(self, eng, q):
+        r, p = self._rank, self._world
+        ex = self._start_exchange(self.E[0] if r > 0 else None, r - 1,
+                                  self._E_above, r + 1)
+        last = self.Nx - 1 if r < p - 1 else self.Nx
+        eng.bulk_H(0, last)
+        if ex is not None:
+            ex.wait()
+        if last < self.Nx:
+            eng.bulk_H(last, self.Nx)    # the plane that reads E_above
+        eng.post_H(q)
+
+    def update_E(self):
+        eng = self._engine
+        eng.prepare()
+        eng.reserve_detectors(1, 0)
+        self._half_step_E(eng, self.time_steps_passed)
+        eng.commit_detectors(1, 0)
+
+    def update_H(self):
+        eng = self._engine
+        eng.prepare()
+        eng.reserve_detectors(0, 1)
+        self._half_step_H(eng, self.time_steps_passed)
+        eng.commit_detectors(0, 1)
+
+    def _advance(self, n):
+        if n <= 0:
+            return
+        eng = self._engine
+        eng.prepare()
+        eng.reserve_detectors(n, n)
+        for s in range(n):
+            q = self.time_steps_passed + s
+            self._half_step_E(eng, q)
+            self._half_step_H(eng, q)
+        eng.commit_detectors(n, n)
+        self.time_steps_passed += n
+
+    def run(self, total_time, progress_bar: bool = False):
+        if isinstance(total_time, float):
+            total_time /= self.time_step
+        self._advance(int(total_time))
+
+    # ------------------------------------------------------------------ output
+    def gather(self, name="E"):
+        """The whole-simulation array ``name`` ("E", "H", ...) as a numpy array on every
+        rank (host copies; meant for checks and small outputs, not for the hot path)."""
+        mine = bd.numpy(getattr(self, name))
+        parts = [None] * self._world
+        dist.all_gather_object(parts, mine, group=self._group)
+        return np.concatenate(parts, axis=0)
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(shape=({self.Nx_global},{self.Ny},{self.Nz}), "
+                f"planes={self.x_offset}:{self.x_offset + self.Nx} on rank {self._rank}/{self._world}, "
+                f"grid_spacing={self.grid_spacing:.2e}, courant_number={self.courant_number:.2f})")

@@ -27,7 +27,7 @@ def _line_indices(grid, x, y, z, convert):
             )
         return [conv(v) for v in x], [conv(v) for v in y], [conv(v) for v in z]
     ends = []
-    for key, n in ((x, grid.Nx), (y, grid.Ny), (z, grid.Nz)):
+    for key, n in ((x, grid.Nx_global), (y, grid.Ny), (z, grid.Nz)):
         if isinstance(key, list):
             key = slice(conv(key[0]), conv(key[-1]), None)
         a = conv(key.start if key.start is not None else 0)
@@ -92,7 +92,10 @@ class PointSource(_Waveform):
 
     def _native_add(self, lib, plan):
         g = self.grid
-        cell = [self.x % g.Nx, self.y % g.Ny, self.z % g.Nz]  # negative indices wrap like Python
+        xl = g._local_x(self.x % g.Nx_global)  # negative indices wrap like Python
+        if xl is None:  # the cell belongs to another x-slab
+            return
+        cell = [xl, self.y % g.Ny, self.z % g.Nz]
         _lib.check(lib.fdtdhip_plan_add_source(
             plan, _lib.SRC_ADD_POINTS, 2, 2, 1, _lib.int32s(cell),
             _lib.doubles([self.amplitude]), *self._wave_args()))
@@ -150,12 +153,17 @@ class LineSource(_Waveform):
 
     def _native_add(self, lib, plan):
         g = self.grid
-        cells = []
-        for x, y, z in zip(self.x, self.y, self.z):
-            cells += [x % g.Nx, y % g.Ny, z % g.Nz]
+        cells, profile = [], []
+        for x, y, z, p in zip(self.x, self.y, self.z, self.profile):
+            xl = g._local_x(x % g.Nx_global)
+            if xl is not None:  # points of other x-slabs are injected there
+                cells += [xl, y % g.Ny, z % g.Nz]
+                profile.append(p)
+        if not profile:
+            return
         _lib.check(lib.fdtdhip_plan_add_source(
-            plan, _lib.SRC_ADD_POINTS, 2, 2, len(self.x), _lib.int32s(cells),
-            _lib.doubles(self.profile), *self._wave_args()))
+            plan, _lib.SRC_ADD_POINTS, 2, 2, len(profile), _lib.int32s(cells),
+            _lib.doubles(profile), *self._wave_args()))
 
     def __repr__(self):
         return (f"{self.__class__.__name__}(period={self.period}, amplitude={self.amplitude}, "
@@ -196,7 +204,7 @@ class PlaneSource:
     def _handle_slices(self, x, y, z):
         g = self.grid
         spans = []
-        for key, n in ((x, g.Nx), (y, g.Ny), (z, g.Nz)):
+        for key, n in ((x, g.Nx_global), (y, g.Ny), (z, g.Nz)):
             if not isinstance(key, slice):
                 if isinstance(key, list):
                     (key,) = key
@@ -238,7 +246,10 @@ class PlaneSource:
                 self.amplitude, self.phase_shift)
 
     def _native_add(self, lib, plan):
-        box = [self.x.start, self.x.stop, self.y.start, self.y.stop, self.z.start, self.z.stop]
+        lo, hi = self.grid._clip_x(self.x.start, self.x.stop)
+        if hi <= lo:
+            return
+        box = [lo, hi, self.y.start, self.y.stop, self.z.start, self.z.stop]
         _lib.check(lib.fdtdhip_plan_add_source(
             plan, _lib.SRC_SET_BOX, self._Epol, self._Hpol, 1, _lib.int32s(box),
             _lib.doubles([self.amplitude]), float(self.period), float(self.phase_shift),

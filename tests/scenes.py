@@ -191,6 +191,43 @@ SCENES = {
 # fmt: on
 
 
+# scenes for the x-slab decomposition tests (components straddle the slab faces)
+SLAB_SCENES = {
+    "slab_mix": dict(
+        grid=dict(shape=(26, 14, 12)),
+        items=[
+            ("pml",         (S(0, 4), S(None), S(None)), {}),
+            ("pml",         (S(-3, None), S(None), S(None)), {}),
+            ("pml",         (S(None), S(0, 3), S(None)), {}),
+            ("pml",         (S(None), S(None), S(-3, None)), {}),
+            ("object",      (S(8, 20), S(4, 9), S(2, 8)), dict(permittivity=("randpos", 21, (12, 5, 6), 1.5, 3.0))),
+            ("anisotropic", (S(5, 23), S(8, 12), S(3, 7)), dict(permittivity=2.0), dict(offdiag_seed=4, offdiag_scale=0.04)),
+            ("absorbing",   (S(15, 19), S(2, 5), S(8, 11)), dict(permittivity=1.5, conductivity=3e4)),
+            ("point",       (13, 7, 6), dict(period=9)),
+            ("point",       (12, 6, 5), dict(period=7, amplitude=0.5)),
+            ("line",        (S(6, 22), S(3, 11), 6), dict(period=11)),
+            ("plane",       (S(9, 18), 10, S(None)), dict(period=13, polarization="z")),
+            ("linedet",     (S(1, 25), 7, 6), {}),
+            ("blockdet",    (S(11, 14), S(6, 7), S(5, 6)), {}),
+        ],
+        steps=30,
+    ),
+    "slab_2d": dict(
+        grid=dict(shape=(31, 17, 1)),
+        items=[
+            ("periodic", (S(None), S(None), 0), {}),
+            ("periodic", (S(None), 0, S(None)), {}),
+            ("pml",      (S(0, 5), S(None), S(None)), {}),
+            ("pml",      (S(-5, None), S(None), S(None)), {}),
+            ("object",   (S(9, 22), S(5, 12), 0), dict(permittivity=2.3)),
+            ("point",    (15, 8, 0), dict(period=10)),
+            ("linedet",  (S(0, 31), 8, 0), {}),
+        ],
+        steps=40,
+    ),
+}
+
+
 def _materialise(v):
     if isinstance(v, tuple) and v and v[0] == "randpos":
         return _randpos(*v[1:])
@@ -209,9 +246,9 @@ def poke_value(grid, poke):
     return float(np.exp(-(((t - center) ** 2.0) / (2.0 * (sigma ** 2.0)))))
 
 
-def build_api(scene, fdtd):
+def build_api(scene, fdtd, grid_factory=None):
     """Build the scene through the public fdtd-style API of module ``fdtd``."""
-    grid = fdtd.Grid(**scene["grid"])
+    grid = (grid_factory or fdtd.Grid)(**scene["grid"])
     made = []
     for item in scene["items"]:
         kind, key, kw = item[0], item[1], dict(item[2])
@@ -243,7 +280,14 @@ def offdiag_values(shape5, extra):
 def fill_offdiag(obj, extra):
     """Add reproducible off-diagonal entries to an anisotropic object's tensor."""
     m = obj.inverse_permittivity
-    vals = offdiag_values(tuple(m.shape), extra)
+    xg = getattr(obj, "x_global", None)
+    if xg is not None and (xg.stop - xg.start) != m.shape[0]:
+        # one x-slab of the object: same numbers as the whole object would get
+        whole = (xg.stop - xg.start,) + tuple(m.shape[1:])
+        first = obj.x.start + obj.grid.x_offset - xg.start
+        vals = offdiag_values(whole, extra)[first:first + m.shape[0]]
+    else:
+        vals = offdiag_values(tuple(m.shape), extra)
     if isinstance(m, np.ndarray):
         m += vals
     else:  # torch tensor of the engine under test

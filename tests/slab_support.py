@@ -1,0 +1,161 @@
+"""Support for the multi-process x-slab tests.
+
+``OracleSlabEngine`` is a TEST DOUBLE for the native engine of
+``fdtd_amd.parallel.SlabGrid``: it executes the half steps of one slab with the
+numpy oracle, directly on the memory of the slab's (host-staging) tensors.  With it
+the CPU suite exercises everything of the multi-GPU path except the HIP kernels:
+plane partitioning, clipping of components to a slab, the collective border-value
+lookup, the exchange schedule and direction, ghost-plane use -- against the
+single-grid oracle run.
+"""
+
+import os
+import socket
+
+import numpy as np
+import torch
+
+from oracle import yee_numpy as orc
+
+
+class OracleSlabEngine:
+    def __init__(self, grid):
+        self.grid = grid
+        self.og = None
+        self.sig = None
+        self.calls = []
+
+    # -- build the oracle twin of the slab from the engine's resolved components
+    def prepare(self):
+        g = self.grid
+        sig = g._signature()
+        if self.og is not None and sig == self.sig:
+            return
+        og = orc.OracleGrid((g.Nx, g.Ny, g.Nz), grid_spacing=g.grid_spacing)
+        og.courant_number, og.time_step = g.courant_number, g.time_step
+        og.E, og.H = g.E.numpy(), g.H.numpy()  # shared memory
+        og.inverse_permittivity = g.inverse_permittivity.numpy()
+        og.inverse_permeability = g.inverse_permeability.numpy()
+        self.dets = []
+        for b in g.boundaries:
+            if hasattr(b, "thickness"):
+                if b._active:
+                    og.add_pml(b.axis, b.side, b.thickness, b.a)
+            else:
+                og.add_periodic(b.axis)
+        for o in g.objects:
+            if o.Nx == 0:
+                continue
+            kind = {0: "object", 1: "absorbing", 2: "anisotropic"}[o._native_kind]
+            box = (o.x.start, o.x.stop, o.y.start, o.y.stop, o.z.start, o.z.stop)
+            oo = og.add_object(box, 1.0, kind=kind, conductivity=0.0)
+            oo.inverse_permittivity = o.inverse_permittivity.detach().numpy()
+            if kind == "absorbing":
+                oo.absorption_factor = o.absorption_factor.numpy()
+        for s in g.sources:
+            name = type(s).__name__
+            if name == "PointSource":
+                xl = g._local_x(s.x)
+                if xl is None:
+                    continue
+                t = og.add_point_source((xl, s.y, s.z), period=s.period, amplitude=s.amplitude,
+                                        phase_shift=s.phase_shift, pulse=s.pulse, cycle=s.cycle,
+                                        hanning_dt=s.hanning_dt)
+                t.wave.frequency = s.frequency
+            elif name == "LineSource":
+                keep = [n for n, x in enumerate(s.x) if g._local_x(x) is not None]
+                if not keep:
+                    continue
+                t = og.add_line_source([g._local_x(s.x[n]) for n in keep], [s.y[n] for n in keep],
+                                       [s.z[n] for n in keep], period=s.period,
+                                       phase_shift=s.phase_shift, pulse=s.pulse, cycle=s.cycle,
+                                       hanning_dt=s.hanning_dt)
+                t.wave.frequency = s.frequency
+                t.profile = np.array([s.profile[n] for n in keep])
+            elif name == "PlaneSource":
+                lo, hi = g._clip_x(s.x.start, s.x.stop)
+                if hi <= lo:
+                    continue
+                og.add_plane_source((lo, hi, s.y.start, s.y.stop, s.z.start, s.z.stop),
+                                    period=s.period, amplitude=s.amplitude,
+                                    phase_shift=s.phase_shift, polarization=s.polarization)
+        for d in g.detectors:
+            name = type(d).__name__
+            if name == "LineDetector":
+                pts = d._local_points()
+                od = og.add_line_detector([p[0] for p in pts], [p[1] for p in pts], [p[2] for p in pts])
+            elif name == "BlockDetector":
+                xs = [g._local_x(x) for x in d.x if g._local_x(x) is not None]
+                od = og.add_block_detector(xs, d.y, d.z)
+            else:
+                xs = [g._local_x(x) for x in d.x if g._local_x(x) is not None]
+                od = og.add_current_detector(xs, d.y, d.z)
+            self.dets.append((d, od))
+        self.og, self.sig = og, sig
+
+    def reserve_detectors(self, nE, nH):
+        pass
+
+    def commit_detectors(self, nE, nH):
+        for d, od in self.dets:
+            for attr in ("E", "H", "I"):
+                if hasattr(od, attr):
+                    src, dst = getattr(od, attr), getattr(d, attr)
+                    while len(dst) < len(src):
+                        dst.append(torch.from_numpy(np.array(src[len(dst)])))
+
+    # -- half-step pieces: ranges are recorded, the oracle acts when the step completes
+    def bulk_E(self, x0, x1):
+        self.calls.append(("E", x0, x1, self._ghost_ready("E")))
+
+    def bulk_H(self, x0, x1):
+        self.calls.append(("H", x0, x1, self._ghost_ready("H")))
+
+    def _ghost_ready(self, phase):
+        g = self.grid
+        ex = getattr(g, "_test_exchange_done", None)
+        return ex
+
+    def _check_cover(self, phase):
+        g = self.grid
+        mine = [(a, b) for p, a, b, _ in self.calls if p == phase and b > a]
+        covered = sorted(mine)
+        pos = 0
+        for a, b in covered:
+            assert a == pos, f"planes {pos}:{a} of the {phase} half step were skipped"
+            pos = b
+        assert pos == g.Nx, f"{phase} half step stopped at plane {pos} of {g.Nx}"
+        # the plane that needs a ghost must be the last one enqueued
+        if phase == "E" and g._H_below is not None and g.Nx > 1:
+            assert mine[-1] == (0, 1)
+        if phase == "H" and g._E_above is not None and g.Nx > 1:
+            assert mine[-1] == (g.Nx - 1, g.Nx)
+        self.calls = [c for c in self.calls if c[0] != phase]
+
+    def post_E(self, q):
+        self._check_cover("E")
+        g, og = self.grid, self.og
+        og.time_steps_passed = q
+        og.halo_lo_H = g._H_below.numpy() if g._H_below is not None else None
+        og.update_E()
+
+    def post_H(self, q):
+        self._check_cover("H")
+        g, og = self.grid, self.og
+        og.time_steps_passed = q
+        og.halo_hi_E = g._E_above.numpy() if g._E_above is not None else None
+        og.update_H()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def init_gloo(rank, world, port):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -1,0 +1,121 @@
+"""x-slab decomposition (the multi-GPU path) against the single-grid run.
+
+CPU part (world sizes 2 and 3, gloo): everything of ``fdtd_amd.parallel.SlabGrid``
+except the HIP kernels, with the numpy oracle as the per-slab engine (test double,
+tests/slab_support.py).  GPU part: two ranks sharing the one GPU of the test box,
+real kernels, planes staged through the host by gloo.
+"""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.dirname(HERE), HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import scenes  # noqa: E402
+import slab_support  # noqa: E402
+
+
+def _worker(rank, world, port, scene_name, on_gpu, out):
+    import torch.distributed as dist
+
+    import fdtd_amd as fdtd
+    from fdtd_amd.parallel import SlabGrid
+
+    slab_support.init_gloo(rank, world, port)
+    try:
+        if on_gpu:
+            fdtd.set_backend("hip.float64", device=0)
+            factory = None
+        else:
+            fdtd.set_backend("hip.float64", device="host-staging")
+            factory = slab_support.OracleSlabEngine
+        scene = scenes.SLAB_SCENES[scene_name]
+        grid, made = scenes.build_api(
+            scene, fdtd, grid_factory=lambda **kw: SlabGrid(engine_factory=factory, **kw))
+        half = scene["steps"] // 2
+        grid.run(half)
+        for _ in range(scene["steps"] - half):  # the half-step entry points too
+            grid.update_E()
+            grid.update_H()
+            grid.time_steps_passed += 1
+        if on_gpu:
+            torch.cuda.synchronize()
+        E, H = grid.gather("E"), grid.gather("H")
+        dets = {}
+        for n, (kind, t, _, _) in enumerate(made):
+            if kind in ("linedet", "blockdet"):
+                mine = fdtd.backend.numpy(t.E) if len(t.E) else np.zeros((0,))
+                parts = [None] * world
+                dist.all_gather_object(parts, (grid.x_offset, mine))
+                dets[n] = parts
+        if rank == 0:
+            np.savez(out, E=E, H=H, **{f"det{n}_{r}": p[1] for n, ps in dets.items() for r, p in enumerate(ps)})
+    finally:
+        dist.destroy_process_group()
+
+
+def _single_grid_oracle(scene):
+    import fdtd_amd as fdtd
+
+    fdtd.set_backend("hip.float64", device="host-staging")
+    g, made = scenes.build_api(scene, fdtd)
+    resolved, arrays = scenes.resolve(scene, g, made)
+    og, omade = scenes.build_oracle(resolved, arrays)
+    scenes.run_oracle(resolved, og)
+    return og, omade
+
+
+def _check(scene_name, world, on_gpu, tmp_path):
+    out = str(tmp_path / f"{scene_name}_{world}.npz")
+    port = slab_support.free_port()
+    mp.spawn(_worker, args=(world, port, scene_name, on_gpu, out), nprocs=world, join=True)
+    z = np.load(out)
+    scene = scenes.SLAB_SCENES[scene_name]
+    og, omade = _single_grid_oracle(scene)
+    tol = 1e-12
+    for name in ("E", "H"):
+        want = getattr(og, name)
+        err = np.linalg.norm((z[name] - want).ravel()) / np.linalg.norm(want.ravel())
+        assert err <= tol, f"{scene_name} x{world}: {name} rel-L2 {err:.3e}"
+    for n, (kind, t) in enumerate(omade):
+        if kind == "linedet":  # points ordered along x: slabs concatenate
+            got = np.concatenate([z[f"det{n}_{r}"] for r in range(world) if z[f"det{n}_{r}"].size], axis=1)
+            want = np.array(t.E)
+            assert np.linalg.norm((got - want).ravel()) <= tol * max(np.linalg.norm(want.ravel()), 1e-30)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("scene_name", sorted(scenes.SLAB_SCENES))
+def test_slabs_equal_single_grid_cpu(scene_name, world, tmp_path):
+    _check(scene_name, world, False, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name", sorted(scenes.SLAB_SCENES))
+def test_slabs_equal_single_grid_gpu(scene_name, tmp_path):
+    _check(scene_name, 2, True, tmp_path)
+
+
+def test_partition_arithmetic():
+    from fdtd_amd.parallel import SlabGrid
+
+    class Fake(SlabGrid):
+        def __init__(self, n, world, rank):
+            self.Nx_global, self._world, self._rank = n, world, rank
+            self._partition()
+
+    for n, world in ((26, 2), (26, 3), (512, 8), (9, 4), (4, 4)):
+        spans = [(f.x_offset, f.x_offset + f.Nx) for f in (Fake(n, world, r) for r in range(world))]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+    with pytest.raises(ValueError):
+        Fake(3, 4, 0)
