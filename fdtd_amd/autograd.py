@@ -1,0 +1,132 @@
+"""Differentiable time stepping: ``grid.run(n)`` as one autograd node.
+
+The reference obtains gradients by letting torch autograd record every slice
+operation of every step (reference examples/learnable_focus.py:98-128 through
+fdtd/objects.py:315-349).  Here a run of ``n`` steps is a single
+``torch.autograd.Function``:
+
+* forward  -- the usual native run on fresh copies of the state (fields and PML
+  memory variables), with the E half step recording, per step, the curl of H
+  inside every learnable anisotropic object (the only forward quantity the
+  gradient of their tensors needs);
+* backward -- ``fdtdhip_adjoint_run``: hand-written reverse-time kernels
+  (``csrc/yee_adjoint.hpp``) propagate dL/dE, dL/dH and dL/dpsi back through the
+  n steps and accumulate dL/d(inverse_permittivity) of the learnable objects.
+
+Differentiable inputs: ``grid.E``, ``grid.H``, the PML memory variables (so that
+consecutive runs chain) and ``obj.inverse_permittivity`` of anisotropic objects
+that require grad.  Material arrays of the grid and sources are constants.
+"""
+
+import ctypes
+
+import torch
+
+from . import _lib
+from .backend import backend as bd
+
+
+def _learnable(grid):
+    return [o for o in grid.objects
+            if o._native_kind == _lib.OBJ_ANISOTROPIC and o.Nx > 0
+            and torch.is_tensor(o.inverse_permittivity) and o.inverse_permittivity.requires_grad]
+
+
+def _active_pmls(grid):
+    return [b for b in grid.boundaries if hasattr(b, "thickness") and b._active]
+
+
+def needs_grad(grid):
+    """True when a run must be recorded for a later backward pass."""
+    if not torch.is_grad_enabled():
+        return False
+    if grid.E.requires_grad or grid.H.requires_grad or _learnable(grid):
+        return True
+    return any(p._psiE.requires_grad or p._psiH.requires_grad for p in _active_pmls(grid))
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _Run(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grid, n, E, H, *rest):
+        objs, pmls = _learnable(grid), _active_pmls(grid)
+        k = len(objs)
+        # the run works on fresh state tensors; the inputs keep their values for autograd
+        grid.E, grid.H = E.detach().clone(), H.detach().clone()
+        psis = [t.detach().clone() for t in rest[k:]]
+        for n_p, p in enumerate(pmls):
+            p._psiE, p._psiH = psis[2 * n_p], psis[2 * n_p + 1]
+        lib = grid._ensure_plan()
+        plan = grid._plan
+        traces = []
+        for o in objs:
+            tr = bd.zeros((n, o.Nx * o.Ny * o.Nz, 3))
+            _lib.check(lib.fdtdhip_plan_set_object_trace(plan, o._native_id, _ptr(tr), n))
+            traces.append(tr)
+        try:
+            for det in grid.detectors:
+                det._reserve(lib, plan, n, n)
+            _lib.check(lib.fdtdhip_run(plan, grid.time_steps_passed, n))
+            for det in grid.detectors:
+                det._commit(n, n)
+        finally:
+            for o in objs:
+                _lib.check(lib.fdtdhip_plan_set_object_trace(plan, o._native_id, None, 0))
+        ctx.grid, ctx.n, ctx.k, ctx.traces = grid, n, k, traces
+        ctx.objs, ctx.pmls = objs, pmls
+        ctx.save_for_backward(*rest[:k])
+        return (grid.E, grid.H, *psis)
+
+    @staticmethod
+    def backward(ctx, gE, gH, *gpsi):
+        grid, n, objs, pmls = ctx.grid, ctx.n, ctx.objs, ctx.pmls
+        params = ctx.saved_tensors
+        full = (grid.Nx, grid.Ny, grid.Nz, 3)
+
+        def start(g, shape):
+            if g is None:
+                return bd.zeros(shape)
+            return g.detach().to(dtype=bd.float).contiguous().clone()
+
+        lamE, lamH = start(gE, full), start(gH, full)
+        lam_psi = [start(g, (2,) + p.shape) for g, p in
+                   zip(gpsi, [q for p in pmls for q in (p, p)])]
+        grads = [torch.zeros_like(p.detach()) for p in params]
+        work = bd.zeros((grid.Nx * grid.Ny * grid.Nz, 6))
+        lib = grid._ensure_plan()
+        plan = grid._plan
+        for o, tr, gr in zip(objs, ctx.traces, grads):
+            _lib.check(lib.fdtdhip_plan_set_object_trace(plan, o._native_id, _ptr(tr), n))
+            _lib.check(lib.fdtdhip_plan_set_object_grad(plan, o._native_id, _ptr(gr)))
+        for n_p, p in enumerate(pmls):
+            _lib.check(lib.fdtdhip_plan_set_pml_adjoint(
+                plan, p._native_id, _ptr(lam_psi[2 * n_p]), _ptr(lam_psi[2 * n_p + 1])))
+        try:
+            _lib.check(lib.fdtdhip_adjoint_run(plan, n, _ptr(lamE), _ptr(lamH), _ptr(work)))
+        finally:
+            for o in objs:
+                _lib.check(lib.fdtdhip_plan_set_object_trace(plan, o._native_id, None, 0))
+                _lib.check(lib.fdtdhip_plan_set_object_grad(plan, o._native_id, None))
+            for p in pmls:
+                _lib.check(lib.fdtdhip_plan_set_pml_adjoint(plan, p._native_id, None, None))
+        return (None, None, lamE, lamH, *grads, *lam_psi)
+
+
+def differentiable_advance(grid, n):
+    """``n`` full steps recorded as one autograd node; re-binds the grid's state tensors
+    to the node's outputs."""
+    if grid.Nx != grid.Nx_global:
+        raise NotImplementedError("differentiable runs are not available on x-slabs")
+    objs, pmls = _learnable(grid), _active_pmls(grid)
+    grid._fields()
+    inputs = [o.inverse_permittivity for o in objs]
+    for p in pmls:
+        inputs += [p._psiE, p._psiH]
+    out = _Run.apply(grid, n, grid.E, grid.H, *inputs)
+    grid.E, grid.H = out[0], out[1]
+    for n_p, p in enumerate(pmls):
+        p._psiE, p._psiH = out[2 + 2 * n_p], out[3 + 2 * n_p]
+    grid.time_steps_passed += n

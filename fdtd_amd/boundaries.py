@@ -235,7 +235,7 @@ class PML(Boundary):
             t = getattr(self, name)
             if t.dtype != bd.float or t.device != bd.device or not t.is_contiguous():
                 setattr(self, name, t.to(device=bd.device, dtype=bd.float).contiguous())
-        _lib.check(lib.fdtdhip_plan_add_pml(
+        self._native_id = _lib.check(lib.fdtdhip_plan_add_pml(
             plan, self.axis, 0 if self.side == "low" else 1, self.thickness,
             _lib.doubles(self._bE1d), _lib.doubles(self._cE1d),
             _lib.doubles(self._bH1d), _lib.doubles(self._cH1d),

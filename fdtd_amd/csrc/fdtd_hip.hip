@@ -18,6 +18,7 @@
 #include "plan.hpp"
 #include "yee_generic.hpp"
 #include "yee_tiled.hpp"
+#include "yee_adjoint.hpp"
 
 namespace {
 
@@ -54,6 +55,8 @@ struct PmlH {
   void* psiH;
   void *bE, *cE, *bH, *cH;  // device arrays of the plan's element type
   bool fused;               // no periodic boundary precedes it in the list
+  void* lamE = nullptr;     // adjoints of psiE / psiH (differentiable runs)
+  void* lamH = nullptr;
 };
 
 struct BoundaryRef {
@@ -66,6 +69,9 @@ struct ObjH {
   int box[6];
   const void* inv;
   const void* absorb;
+  void* trace = nullptr;       // (capacity, box, 3) curl trace of a differentiable run
+  int64_t trace_capacity = 0;
+  void* grad = nullptr;        // gradient accumulator for `inv`
 };
 
 struct SourceH {
@@ -106,7 +112,9 @@ struct fdtdhip_plan {
   std::vector<SourceH> sources;
   std::vector<DetH> dets;
   void* obj_table = nullptr;  // device ObjK<T>[]
+  size_t obj_table_bytes = 0;
   bool obj_dirty = false;
+  int64_t trace_cursor = -1;  // row of the curl traces the next E half step writes; -1: no traces
   std::vector<void*> owned;   // device allocations released by reset/destroy
   // optional kernel timing (fdtdhip_plan_enable_timing)
   bool timing = false;
@@ -129,6 +137,8 @@ int release_tables(fdtdhip_plan* p) {
   p->owned.clear();
   if (p->obj_table) (void)hipFree(p->obj_table);
   p->obj_table = nullptr;
+  p->obj_table_bytes = 0;
+  p->trace_cursor = -1;
   p->boundaries.clear();
   p->pmls.clear();
   p->objs.clear();
@@ -153,26 +163,33 @@ int upload_profile(fdtdhip_plan* p, const double* host, int n, void** out) {
 template <typename T>
 int sync_obj_table(fdtdhip_plan* p) {
   if (!p->obj_dirty) return 0;
-  if (p->obj_table) {
-    // the table may still be read by kernels in flight on the plan's stream
-    HIPCHK(hipStreamSynchronize(p->stream));
-    HIPCHK(hipFree(p->obj_table));
-    p->obj_table = nullptr;
-  }
   std::vector<ObjK<T>> tab(p->objs.size());
   for (size_t o = 0; o < p->objs.size(); ++o) {
     const ObjH& h = p->objs[o];
     tab[o].inv = (const T*)h.inv;
     tab[o].absorb = (const T*)h.absorb;
+    tab[o].trace = (T*)h.trace;
+    tab[o].grad = (T*)h.grad;
     tab[o].kind = h.kind;
     tab[o].x0 = h.box[0]; tab[o].x1 = h.box[1];
     tab[o].y0 = h.box[2]; tab[o].y1 = h.box[3];
     tab[o].z0 = h.box[4]; tab[o].z1 = h.box[5];
   }
+  const size_t bytes = sizeof(ObjK<T>) * tab.size();
+  if (p->obj_table && p->obj_table_bytes != bytes) {
+    // the old table may still be read by kernels in flight on the plan's stream
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipFree(p->obj_table));
+    p->obj_table = nullptr;
+  }
   if (!tab.empty()) {
-    HIPCHK(hipMalloc(&p->obj_table, sizeof(ObjK<T>) * tab.size()));
-    HIPCHK(hipMemcpy(p->obj_table, tab.data(), sizeof(ObjK<T>) * tab.size(),
-                     hipMemcpyHostToDevice));
+    if (!p->obj_table) {
+      HIPCHK(hipMalloc(&p->obj_table, bytes));
+      p->obj_table_bytes = bytes;
+    }
+    // stream-ordered update, completed before the host copy goes out of scope
+    HIPCHK(hipMemcpyAsync(p->obj_table, tab.data(), bytes, hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
   }
   p->obj_dirty = false;
   return 0;
@@ -285,6 +302,7 @@ int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
   a.npml = (int)p->pmls.size();
   a.nobj = phaseE ? (int)p->objs.size() : 0;
   a.obj = (const ObjK<T>*)p->obj_table;
+  a.trace_step = phaseE ? p->trace_cursor : -1;
   for (int i = 0; i < a.npml; ++i) a.pml[i] = make_pmlk<T>(p, p->pmls[i], phaseE);
 
   const bool pml = a.npml > 0, obj = a.nobj > 0;
@@ -365,6 +383,11 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q) {
   T* F = (T*)(phaseE ? p->E : p->H);
   const T* mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
   if (!F || !mat) return fail(-1, "fields not set");
+  if (phaseE && p->trace_cursor >= 0) {  // the E bulk pass of this step filled one trace row
+    ++p->trace_cursor;
+    for (const ObjH& o : p->objs)
+      if (o.trace && p->trace_cursor >= o.trace_capacity) p->trace_cursor = -1;  // traces full
+  }
   // boundaries that follow the first periodic one, in list order
   bool seen_periodic = false;
   for (const BoundaryRef& b : p->boundaries) {
@@ -434,6 +457,87 @@ int curl_launch(const void* in, void* out, int nx, int ny, int nz, bool forward,
     hipLaunchKernelGGL((curl_only<T, false>), dim3(blocks_for(n)), dim3(256), 0,
                        (hipStream_t)stream, (const T*)in, (T*)out, nx, ny, nz);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// One reverse step of the adjoint recursion: undo the H half step, then the E half step
+// (each: reverse of the post pieces, pass 1 per cell, pass 2 gather).
+template <typename T>
+int adjoint_half(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
+  T* lamF = phaseE ? lamE : lamH;
+  T* lamG = phaseE ? lamH : lamE;
+  const T* mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
+  // reverse of post(): sources (hard assignments kill the adjoint), then the boundaries
+  // that follow the first periodic one, last first
+  for (auto it = p->sources.rbegin(); it != p->sources.rend(); ++it) {
+    const SourceH& s = *it;
+    if (s.kind != FDTDHIP_SRC_SET_BOX) continue;
+    const int64_t total =
+        (int64_t)(s.box[1] - s.box[0]) * (s.box[3] - s.box[2]) * (s.box[5] - s.box[4]);
+    if (total <= 0) continue;
+    hipLaunchKernelGGL((source_set_box<T>), dim3(blocks_for(total)), dim3(256), 0, p->stream, lamF,
+                       p->ny, p->nz, s.box[0], s.box[1], s.box[2], s.box[3], s.box[4], s.box[5],
+                       phaseE ? s.compE : s.compH, T(0));
+  }
+  size_t first_periodic = p->boundaries.size();
+  for (size_t b = 0; b < p->boundaries.size(); ++b)
+    if (p->boundaries[b].kind == 1) { first_periodic = b; break; }
+  for (size_t b = p->boundaries.size(); b-- > first_periodic;) {
+    const BoundaryRef& br = p->boundaries[b];
+    if (br.kind == 1) {
+      const int axis = br.idx;
+      const int n = axis == 0 ? p->nx : (axis == 1 ? p->ny : p->nz);
+      if (n < 2) continue;
+      const int64_t total = p->cells() / n * 3;
+      const int dst = phaseE ? 0 : n - 1, src = phaseE ? n - 1 : 0;
+      hipLaunchKernelGGL((adj_periodic_copy<T>), dim3(blocks_for(total)), dim3(256), 0, p->stream,
+                         lamF, p->nx, p->ny, p->nz, axis, dst, src);
+    } else {
+      const PmlH& h = p->pmls[br.idx];
+      PmlK<T> k = make_pmlk<T>(p, h, phaseE);
+      k.psi = (T*)(phaseE ? h.lamE : h.lamH);
+      if (!k.psi) return fail(-1, "PML adjoint arrays not set");
+      const int64_t slab = (int64_t)(h.axis == 0 ? h.t : p->nx) * k.sy * k.sz;
+      hipLaunchKernelGGL((adj_pml_apply_slab<T>), dim3(blocks_for(slab)), dim3(256), 0, p->stream,
+                         lamF, mat, k, p->nx, p->ny, p->nz, (T)p->sc, phaseE ? T(1) : T(-1));
+    }
+  }
+  AdjArgs<T> a;
+  a.lamF = lamF; a.lamG = lamG; a.mat = mat; a.work = work;
+  a.nx = p->nx; a.ny = p->ny; a.nz = p->nz;
+  a.sc = (T)p->sc;
+  a.npml = (int)p->pmls.size();
+  a.nobj = phaseE ? (int)p->objs.size() : 0;
+  a.obj = (const ObjK<T>*)p->obj_table;
+  a.trace_step = phaseE ? p->trace_cursor : -1;
+  for (int i = 0; i < a.npml; ++i) {
+    a.pml[i] = make_pmlk<T>(p, p->pmls[i], phaseE);
+    a.pml[i].psi = (T*)(phaseE ? p->pmls[i].lamE : p->pmls[i].lamH);
+    if (!a.pml[i].psi) return fail(-1, "PML adjoint arrays not set");
+  }
+  const dim3 grid(blocks_for(p->cells())), block(256);
+  if (phaseE) {
+    hipLaunchKernelGGL((adj_E_cells<T>), grid, block, 0, p->stream, a);
+    hipLaunchKernelGGL((adj_gather<T, true>), grid, block, 0, p->stream, a);
+  } else {
+    hipLaunchKernelGGL((adj_H_cells<T>), grid, block, 0, p->stream, a);
+    hipLaunchKernelGGL((adj_gather<T, false>), grid, block, 0, p->stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH, void* work) {
+  if (!p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
+  if (p->H_below || p->E_above) return fail(-1, "the adjoint is not available on x-slabs");
+  if (int rc = sync_obj_table<T>(p)) return rc;
+  for (int64_t s = nsteps - 1; s >= 0; --s) {
+    p->trace_cursor = s;
+    if (int rc = adjoint_half<T>(p, false, (T*)lamE, (T*)lamH, (T*)work)) return rc;
+    if (int rc = adjoint_half<T>(p, true, (T*)lamE, (T*)lamH, (T*)work)) return rc;
+  }
+  p->trace_cursor = -1;
   return 0;
 }
 
@@ -539,7 +643,7 @@ int fdtdhip_plan_add_pml(fdtdhip_plan* p, int axis, int side, int t, const doubl
   }
   p->pmls.push_back(h);
   p->boundaries.push_back({0, (int)p->pmls.size() - 1});
-  return 0;
+  return (int)p->pmls.size() - 1;
 }
 
 int fdtdhip_plan_add_periodic(fdtdhip_plan* p, int axis) {
@@ -566,7 +670,7 @@ int fdtdhip_plan_add_object(fdtdhip_plan* p, int kind, const int32_t box[6], con
   h.absorb = absorb;
   p->objs.push_back(h);
   p->obj_dirty = true;
-  return 0;
+  return (int)p->objs.size() - 1;
 }
 
 int fdtdhip_plan_add_source(fdtdhip_plan* p, int kind, int compE, int compH, int64_t n,
@@ -698,6 +802,44 @@ int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
     if (int rc = fdtdhip_update_H(p, q0 + s)) return rc;
   }
   return 0;
+}
+
+int fdtdhip_plan_set_object_trace(fdtdhip_plan* p, int id, void* trace, int64_t capacity) {
+  if (!p) return fail(-1, "null plan");
+  if (id < 0 || id >= (int)p->objs.size()) return fail(-1, "unknown object id");
+  if (p->objs[id].kind != FDTDHIP_OBJ_ANISOTROPIC)
+    return fail(-1, "curl traces exist for anisotropic objects only");
+  p->objs[id].trace = trace;
+  p->objs[id].trace_capacity = trace ? capacity : 0;
+  p->obj_dirty = true;
+  p->trace_cursor = -1;
+  for (const ObjH& o : p->objs)
+    if (o.trace && o.trace_capacity > 0) p->trace_cursor = 0;
+  return 0;
+}
+
+int fdtdhip_plan_set_object_grad(fdtdhip_plan* p, int id, void* grad) {
+  if (!p) return fail(-1, "null plan");
+  if (id < 0 || id >= (int)p->objs.size()) return fail(-1, "unknown object id");
+  p->objs[id].grad = grad;
+  p->obj_dirty = true;
+  return 0;
+}
+
+int fdtdhip_plan_set_pml_adjoint(fdtdhip_plan* p, int id, void* lam_psiE, void* lam_psiH) {
+  if (!p) return fail(-1, "null plan");
+  if (id < 0 || id >= (int)p->pmls.size()) return fail(-1, "unknown PML id");
+  p->pmls[id].lamE = lam_psiE;
+  p->pmls[id].lamH = lam_psiH;
+  return 0;
+}
+
+int fdtdhip_adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH, void* work) {
+  if (!p) return fail(-1, "null plan");
+  if (!lamE || !lamH || !work) return fail(-1, "null adjoint array");
+  DeviceGuard g(p->device);
+  return DISPATCH(p, adjoint_run<float>(p, nsteps, lamE, lamH, work),
+                  adjoint_run<double>(p, nsteps, lamE, lamH, work));
 }
 
 int fdtdhip_plan_enable_timing(fdtdhip_plan* p, int on) {

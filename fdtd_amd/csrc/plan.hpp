@@ -33,6 +33,9 @@ template <typename T>
 struct ObjK {
   const T* inv;     // (box,3) or (box,3,3)
   const T* absorb;  // (box,3) or null
+  T* trace;         // differentiable runs: (steps, box, 3) curl of the driving field inside the
+                    // box, written by the forward E half step, read by the adjoint; or null
+  T* grad;          // adjoint: accumulated gradient of the loss w.r.t. `inv`, same shape; or null
   int kind;
   int x0, x1, y0, y1, z0, z1;
 };
@@ -51,7 +54,25 @@ struct BulkArgs {
   int npml;
   int nobj;
   const ObjK<T>* obj;
+  int64_t trace_step;  // row of the objects' curl traces to write (forward) / read (adjoint); -1: none
   PmlK<T> pml[MAX_PML];
+};
+
+// Arguments of the adjoint (reverse-time) half-step kernels.  For the adjoint of
+// the E half step `lamF` is the adjoint of E and `lamG` the adjoint of H.
+template <typename T>
+struct AdjArgs {
+  T* lamF;         // in/out: adjoint of the field the forward half step advanced
+  T* lamG;         // accumulated: adjoint of the driving field
+  const T* mat;
+  T* work;         // (cells, 6) adjoints of the six neighbour differences
+  int nx, ny, nz;
+  T sc;
+  int npml;
+  int nobj;
+  const ObjK<T>* obj;
+  int64_t trace_step;
+  PmlK<T> pml[MAX_PML];  // psi -> adjoint of the memory variables
 };
 
 }  // namespace fdtdhip

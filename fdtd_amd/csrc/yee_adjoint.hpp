@@ -1,0 +1,249 @@
+// Reverse-time (adjoint) Yee half steps for differentiable runs.
+//
+// The forward half steps are linear in the fields, so the adjoint recursion needs
+// no forward field history; the only forward quantity it needs is the curl of H
+// inside learnable anisotropic objects (for the gradient with respect to their
+// inverse-permittivity tensors), which the forward E half step records per step
+// (ObjK::trace).  This replaces the reference's autograd tape over every slice
+// operation of every step (reference examples/learnable_focus.py:98-128 running
+// through fdtd/objects.py:342-349).
+//
+// Each adjoint half step is two kernels:
+//   pass 1 (per cell): adjoint of everything the forward bulk kernel did at that
+//           cell after forming the six neighbour differences -> the adjoints of
+//           those differences (work[cell][6]), the gradient contribution of
+//           learnable objects, the adjoint of the PML memory variables;
+//   pass 2 (per cell): transpose of the difference stencil as a gather from
+//           `work`, added to the adjoint of the driving field.
+// No atomics: results are reproducible bit for bit.
+#pragma once
+
+#include "plan.hpp"
+
+namespace fdtdhip {
+
+// order of the six difference adjoints in `work`
+enum { WX_Y = 0, WX_Z = 1, WY_X = 2, WY_Z = 3, WZ_X = 4, WZ_Y = 5 };
+
+template <typename T, int AXIS>
+__device__ __forceinline__ void adj_pml_face(const PmlK<T>& P, int nx, int i, int j, int k,
+                                             bool phaseE, T sc, const T lam[3], const T m[3],
+                                             T& GdFu, T& GdFv) {
+  constexpr int u = (AXIS + 1) % 3, v = (AXIS + 2) % 3;
+  const int coord = AXIS == 0 ? i : (AXIS == 1 ? j : k);
+  const int l = coord - P.lo;
+  if (l < 0 || l >= P.t) return;
+  const int li = AXIS == 0 ? l : i, lj = AXIS == 1 ? l : j, lk = AXIS == 2 ? l : k;
+  const int64_t s = ((int64_t)li * P.sy + lj) * P.sz + lk;
+  const int64_t slab = (int64_t)(AXIS == 0 ? P.t : nx) * P.sy * P.sz;
+  T lp0 = P.psi[s], lp1 = P.psi[slab + s];  // adjoint of the updated memory variables
+  if (P.fused) {
+    // forward: F_u += sign*(sc*m_u)*(-psi0'), F_v += sign*(sc*m_v)*psi1', sign = +1 (E) / -1 (H)
+    const T sg = phaseE ? T(1) : T(-1);
+    lp0 += sg * (-(sc * m[u])) * lam[u];
+    lp1 += sg * (sc * m[v]) * lam[v];
+  }
+  // forward: psi0' = b*psi0 + gate*c*dFv ; psi1' = b*psi1 + gate*c*dFu
+  if (phaseE ? (l >= 1) : (l <= P.t - 2)) {
+    GdFv += P.c[l] * lp0;
+    GdFu += P.c[l] * lp1;
+  }
+  P.psi[s] = P.b[l] * lp0;
+  P.psi[slab + s] = P.b[l] * lp1;
+}
+
+// Pass 1 of the adjoint of the E half step.
+template <typename T>
+__global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
+  const int64_t plane = (int64_t)a.ny * a.nz;
+  const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= plane * a.nx) return;
+  const int i = (int)(cell / plane);
+  const int64_t r = cell % plane;
+  const int j = (int)(r / a.nz), k = (int)(r % a.nz);
+  const int64_t c3 = cell * 3;
+  T lam[3] = {a.lamF[c3], a.lamF[c3 + 1], a.lamF[c3 + 2]};
+  const T m[3] = {a.mat[c3], a.mat[c3 + 1], a.mat[c3 + 2]};
+  T G[6] = {0, 0, 0, 0, 0, 0};
+
+  // PML corrections and memory variables (they act on the final E of the half step)
+#pragma unroll
+  for (int p = MAX_PML - 1; p >= 0; --p) {
+    if (p >= a.npml) continue;
+    const PmlK<T>& P = a.pml[p];
+    if (P.axis == 0) adj_pml_face<T, 0>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WX_Y], G[WX_Z]);
+    else if (P.axis == 1) adj_pml_face<T, 1>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WY_Z], G[WY_X]);
+    else adj_pml_face<T, 2>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WZ_X], G[WZ_Y]);
+  }
+
+  // objects, last registered first
+  T g[3] = {0, 0, 0};
+  for (int o = a.nobj - 1; o >= 0; --o) {
+    const ObjK<T> O = a.obj[o];
+    if (i < O.x0 || i >= O.x1 || j < O.y0 || j >= O.y1 || k < O.z0 || k >= O.z1) continue;
+    const int64_t oc =
+        ((int64_t)(i - O.x0) * (O.y1 - O.y0) + (j - O.y0)) * (O.z1 - O.z0) + (k - O.z0);
+    if (O.kind == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g[c] += (a.sc * O.inv[oc * 3 + c]) * lam[c];
+    } else if (O.kind == 1) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const T f = O.absorb[oc * 3 + c];
+        g[c] += ((a.sc * O.inv[oc * 3 + c]) / (T(1) + f)) * lam[c];
+        lam[c] *= (T(1) - f) / (T(1) + f);
+      }
+    } else {
+      const T* M = O.inv + oc * 9;
+#pragma unroll
+      for (int dcol = 0; dcol < 3; ++dcol) {
+        T s = M[0 * 3 + dcol] * lam[0];
+        s += M[1 * 3 + dcol] * lam[1];
+        s += M[2 * 3 + dcol] * lam[2];
+        g[dcol] += a.sc * s;
+      }
+      if (O.grad && O.trace && a.trace_step >= 0) {
+        const int64_t box = (int64_t)(O.x1 - O.x0) * (O.y1 - O.y0) * (O.z1 - O.z0);
+        const T* cu = O.trace + (a.trace_step * box + oc) * 3;
+        T* gr = O.grad + oc * 9;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+          for (int dcol = 0; dcol < 3; ++dcol) gr[rr * 3 + dcol] += (a.sc * lam[rr]) * cu[dcol];
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) g[c] += (a.sc * m[c]) * lam[c];
+
+  // curl: cu0 = d.y_z - d.z_y, cu1 = d.z_x - d.x_z, cu2 = d.x_y - d.y_x
+  G[WY_Z] += g[0]; G[WZ_Y] -= g[0];
+  G[WZ_X] += g[1]; G[WX_Z] -= g[1];
+  G[WX_Y] += g[2]; G[WY_X] -= g[2];
+  // differences the forward pass dropped at the low edges carry no adjoint
+  if (i == 0) G[WX_Y] = G[WX_Z] = 0;
+  if (j == 0) G[WY_X] = G[WY_Z] = 0;
+  if (k == 0) G[WZ_X] = G[WZ_Y] = 0;
+
+  T* w = a.work + cell * 6;
+#pragma unroll
+  for (int n = 0; n < 6; ++n) w[n] = G[n];
+  a.lamF[c3] = lam[0];
+  a.lamF[c3 + 1] = lam[1];
+  a.lamF[c3 + 2] = lam[2];
+}
+
+// Pass 1 of the adjoint of the H half step (no objects act in that half step).
+template <typename T>
+__global__ __launch_bounds__(256) void adj_H_cells(AdjArgs<T> a) {
+  const int64_t plane = (int64_t)a.ny * a.nz;
+  const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= plane * a.nx) return;
+  const int i = (int)(cell / plane);
+  const int64_t r = cell % plane;
+  const int j = (int)(r / a.nz), k = (int)(r % a.nz);
+  const int64_t c3 = cell * 3;
+  const T lam[3] = {a.lamF[c3], a.lamF[c3 + 1], a.lamF[c3 + 2]};
+  const T m[3] = {a.mat[c3], a.mat[c3 + 1], a.mat[c3 + 2]};
+  T G[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int p = MAX_PML - 1; p >= 0; --p) {
+    if (p >= a.npml) continue;
+    const PmlK<T>& P = a.pml[p];
+    if (P.axis == 0) adj_pml_face<T, 0>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WX_Y], G[WX_Z]);
+    else if (P.axis == 1) adj_pml_face<T, 1>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WY_Z], G[WY_X]);
+    else adj_pml_face<T, 2>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WZ_X], G[WZ_Y]);
+  }
+  T g[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) g[c] = -((a.sc * m[c]) * lam[c]);  // H' = H - (sc*mu)*curl
+  G[WY_Z] += g[0]; G[WZ_Y] -= g[0];
+  G[WZ_X] += g[1]; G[WX_Z] -= g[1];
+  G[WX_Y] += g[2]; G[WY_X] -= g[2];
+  if (i == a.nx - 1) G[WX_Y] = G[WX_Z] = 0;
+  if (j == a.ny - 1) G[WY_X] = G[WY_Z] = 0;
+  if (k == a.nz - 1) G[WZ_X] = G[WZ_Y] = 0;
+  T* w = a.work + cell * 6;
+#pragma unroll
+  for (int n = 0; n < 6; ++n) w[n] = G[n];
+}
+
+// Pass 2: transpose of the difference stencil.
+//   E half step: d_a_w(x) = H_w(x) - H_w(x - e_a)  =>  lamH_w(x) += G_a_w(x) - G_a_w(x + e_a)
+//   H half step: d_a_w(x) = E_w(x + e_a) - E_w(x)  =>  lamE_w(x) += G_a_w(x - e_a) - G_a_w(x)
+template <typename T, bool PHASE_E>
+__global__ __launch_bounds__(256) void adj_gather(AdjArgs<T> a) {
+  const int64_t plane = (int64_t)a.ny * a.nz;
+  const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= plane * a.nx) return;
+  const int i = (int)(cell / plane);
+  const int64_t r = cell % plane;
+  const int j = (int)(r / a.nz), k = (int)(r % a.nz);
+  const T* w = a.work + cell * 6;
+  const int64_t sx = plane * 6, sy = (int64_t)a.nz * 6, sz = 6;
+  auto nb = [&](bool ok, int64_t off, int which) { return ok ? w[off + which] : T(0); };
+  T add[3];
+  if (PHASE_E) {
+    const bool ox = i < a.nx - 1, oy = j < a.ny - 1, oz = k < a.nz - 1;
+    add[0] = (w[WY_X] - nb(oy, sy, WY_X)) + (w[WZ_X] - nb(oz, sz, WZ_X));
+    add[1] = (w[WX_Y] - nb(ox, sx, WX_Y)) + (w[WZ_Y] - nb(oz, sz, WZ_Y));
+    add[2] = (w[WX_Z] - nb(ox, sx, WX_Z)) + (w[WY_Z] - nb(oy, sy, WY_Z));
+  } else {
+    const bool ox = i > 0, oy = j > 0, oz = k > 0;
+    add[0] = (nb(oy, -sy, WY_X) - w[WY_X]) + (nb(oz, -sz, WZ_X) - w[WZ_X]);
+    add[1] = (nb(ox, -sx, WX_Y) - w[WX_Y]) + (nb(oz, -sz, WZ_Y) - w[WZ_Y]);
+    add[2] = (nb(ox, -sx, WX_Z) - w[WX_Z]) + (nb(oy, -sy, WY_Z) - w[WY_Z]);
+  }
+  T* out = a.lamG + cell * 3;
+  out[0] += add[0];
+  out[1] += add[1];
+  out[2] += add[2];
+}
+
+// Adjoint of pml_apply_slab (a PML whose correction follows a periodic copy):
+// only the memory-variable adjoints change; the recursion itself is undone in pass 1.
+template <typename T>
+__global__ void adj_pml_apply_slab(const T* lamF, const T* mat, PmlK<T> P, int nx, int ny, int nz,
+                                   T sc, T sign) {
+  const int sx = P.axis == 0 ? P.t : nx;
+  const int64_t slab = (int64_t)sx * P.sy * P.sz;
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= slab) return;
+  const int lk = (int)(s % P.sz);
+  const int lj = (int)((s / P.sz) % P.sy);
+  const int li = (int)(s / ((int64_t)P.sz * P.sy));
+  const int i = P.axis == 0 ? li + P.lo : li, j = P.axis == 1 ? lj + P.lo : lj,
+            k = P.axis == 2 ? lk + P.lo : lk;
+  const int64_t c3 = (((int64_t)i * ny + j) * nz + k) * 3;
+  const int u = (P.axis + 1) % 3, v = (P.axis + 2) % 3;
+  P.psi[s] += sign * (-(sc * mat[c3 + u])) * lamF[c3 + u];
+  P.psi[slab + s] += sign * (sc * mat[c3 + v]) * lamF[c3 + v];
+}
+
+// Adjoint of periodic_copy F[dst] = F[src]:  lam[src] += lam[dst]; lam[dst] = 0.
+template <typename T>
+__global__ void adj_periodic_copy(T* lam, int nx, int ny, int nz, int axis, int dst, int src) {
+  const int n1 = axis == 0 ? ny : nx;
+  const int n2 = axis == 2 ? ny : nz;
+  const int64_t total = (int64_t)n1 * n2 * 3;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int c = (int)(t % 3);
+  const int b = (int)((t / 3) % n2);
+  const int aa = (int)(t / (3 * (int64_t)n2));
+  int64_t d, s;
+  if (axis == 0) {
+    d = (((int64_t)dst * ny + aa) * nz + b) * 3 + c;
+    s = (((int64_t)src * ny + aa) * nz + b) * 3 + c;
+  } else if (axis == 1) {
+    d = (((int64_t)aa * ny + dst) * nz + b) * 3 + c;
+    s = (((int64_t)aa * ny + src) * nz + b) * 3 + c;
+  } else {
+    d = (((int64_t)aa * ny + b) * nz + dst) * 3 + c;
+    s = (((int64_t)aa * ny + b) * nz + src) * 3 + c;
+  }
+  lam[s] += lam[d];
+  lam[d] = 0;
+}
+
+}  // namespace fdtdhip

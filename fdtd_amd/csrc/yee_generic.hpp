@@ -110,6 +110,12 @@ __device__ __forceinline__ void finish_E(const BulkArgs<T>& a, int i, int j, int
           e[c] += ((a.sc * O.inv[oc * 3 + c]) * cu[c]) / (T(1) + f);
         }
       } else {
+        if (O.trace && a.trace_step >= 0) {  // differentiable run: keep the curl for the adjoint
+          const int64_t box =
+              (int64_t)(O.x1 - O.x0) * (O.y1 - O.y0) * (O.z1 - O.z0);
+          T* tr = O.trace + (a.trace_step * box + oc) * 3;
+          tr[0] = cu[0]; tr[1] = cu[1]; tr[2] = cu[2];
+        }
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr) {
           const T* M = O.inv + oc * 9 + rr * 3;

@@ -285,6 +285,7 @@ class Grid:
     # --------------------------------------------------------------- stepping
     def update_E(self):
         """One electric half step (reference fdtd/grid.py:275-299)."""
+        self._no_half_step_autograd()
         lib = self._ensure_plan()
         for det in self.detectors:
             det._reserve(lib, self._plan, 1, 0)
@@ -294,6 +295,7 @@ class Grid:
 
     def update_H(self):
         """One magnetic half step (reference fdtd/grid.py:301-325)."""
+        self._no_half_step_autograd()
         lib = self._ensure_plan()
         for det in self.detectors:
             det._reserve(lib, self._plan, 0, 1)
@@ -301,12 +303,25 @@ class Grid:
         for det in self.detectors:
             det._commit(0, 1)
 
+    def _no_half_step_autograd(self):
+        from . import autograd
+
+        if not bd.staging and autograd.needs_grad(self):
+            raise NotImplementedError(
+                "gradients are recorded per full step: call grid.step() / grid.run(n) "
+                "(or wrap the half steps in torch.no_grad())")
+
     def step(self):
         """One full step: E half step, H half step (reference fdtd/grid.py:267-273)."""
         self._advance(1)
 
     def _advance(self, n):
         if n <= 0:
+            return
+        from . import autograd
+
+        if not bd.staging and autograd.needs_grad(self):
+            autograd.differentiable_advance(self, n)
             return
         lib = self._ensure_plan()
         for det in self.detectors:

@@ -116,7 +116,7 @@ class Object:
     def _native_add(self, lib, plan):
         if self.Nx == 0:  # no cell of the box lies in this x-slab
             return
-        _lib.check(lib.fdtdhip_plan_add_object(
+        self._native_id = _lib.check(lib.fdtdhip_plan_add_object(
             plan, self._native_kind, _lib.int32s(self._box()),
             ctypes.c_void_p(self._tensor("inverse_permittivity").data_ptr()), None))
 
@@ -158,7 +158,7 @@ class AbsorbingObject(Object):
     def _native_add(self, lib, plan):
         if self.Nx == 0:
             return
-        _lib.check(lib.fdtdhip_plan_add_object(
+        self._native_id = _lib.check(lib.fdtdhip_plan_add_object(
             plan, self._native_kind, _lib.int32s(self._box()),
             ctypes.c_void_p(self._tensor("inverse_permittivity").data_ptr()),
             ctypes.c_void_p(self._tensor("absorption_factor").data_ptr())))

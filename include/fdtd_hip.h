@@ -96,7 +96,7 @@ int fdtdhip_plan_set_halo(fdtdhip_plan* plan, const void* H_below, const void* E
  * variables that can be non-zero for this face, [0] = psi_{E,u}[..., axis],
  * [1] = psi_{E,v}[..., axis] with u = (axis+1)%3, v = (axis+2)%3
  * (boundaries.py:437-444, 465-472).  Boundaries act in the order added
- * (grid.py:279-291). */
+ * (grid.py:279-291).  Returns the PML id (>= 0). */
 int fdtdhip_plan_add_pml(fdtdhip_plan* plan, int axis, int side, int thickness,
                          const double* bE, const double* cE, const double* bH,
                          const double* cH, void* psiE, void* psiH);
@@ -108,7 +108,8 @@ int fdtdhip_plan_add_periodic(fdtdhip_plan* plan, int axis);
  * 204-218, 251-266).  inv: device (bx,by,bz,3), or (bx,by,bz,3,3) for
  * FDTDHIP_OBJ_ANISOTROPIC.  absorb: device (bx,by,bz,3) absorption factor
  * (objects.py:195-202) for FDTDHIP_OBJ_ABSORBING, else NULL.  The caller has
- * already zeroed the grid's inverse permittivity in the box (objects.py:90). */
+ * already zeroed the grid's inverse permittivity in the box (objects.py:90).
+ * Returns the object id (>= 0). */
 int fdtdhip_plan_add_object(fdtdhip_plan* plan, int kind, const int32_t box[6],
                             const void* inv, const void* absorb);
 
@@ -157,6 +158,29 @@ int fdtdhip_update_H_post(fdtdhip_plan* plan, int64_t q);
 
 /* nsteps full steps starting at time index q0 (reference fdtd/grid.py:250-273). */
 int fdtdhip_run(fdtdhip_plan* plan, int64_t q0, int64_t nsteps);
+
+/* ---- differentiable runs (backward through time) ---------------------------
+ * The reference differentiates through grid.run with torch autograd, recording
+ * every slice operation of every step (reference examples/learnable_focus.py:98-128,
+ * fdtd/objects.py:315-349).  Here the time stepping is linear in the fields, so
+ * the backward pass is the adjoint recursion run by hand-written reverse-time
+ * kernels; the only forward data it needs is the curl of H inside learnable
+ * anisotropic objects, one (box,3) row per step.
+ *
+ * fdtdhip_plan_set_object_trace: device array of capacity*(box*3) elements in which
+ *   the following E half steps record that curl for object `id` (row 0 first);
+ *   NULL stops recording.
+ * fdtdhip_plan_set_object_grad: device array shaped like the object's `inv`
+ *   (box,3,3) to which the adjoint run ADDS dLoss/d(inv).
+ * fdtdhip_plan_set_pml_adjoint: device arrays shaped like psiE / psiH holding, on
+ *   entry, dLoss/d(psi) after the run and, on return, dLoss/d(psi) before it.
+ * fdtdhip_adjoint_run: lamE, lamH (nx,ny,nz,3) hold dLoss/dE, dLoss/dH after the
+ *   last of `nsteps` recorded steps on entry and before the first one on return;
+ *   `work` is a scratch array of cells*6 elements.  Single-device grids only. */
+int fdtdhip_plan_set_object_trace(fdtdhip_plan* plan, int id, void* trace, int64_t capacity);
+int fdtdhip_plan_set_object_grad(fdtdhip_plan* plan, int id, void* grad);
+int fdtdhip_plan_set_pml_adjoint(fdtdhip_plan* plan, int id, void* lam_psiE, void* lam_psiH);
+int fdtdhip_adjoint_run(fdtdhip_plan* plan, int64_t nsteps, void* lamE, void* lamH, void* work);
 
 /* Kernel timing for benchmarks (the reference only has wall-clock timing around
  * grid.run, examples/old/simulation_benchmark.py:96-107).  While enabled, every

@@ -228,6 +228,53 @@ SLAB_SCENES = {
 }
 
 
+# scenes for the differentiable (adjoint) runs; "learnable" = LearnableAnisotropicObject.
+# loss = sum(WE * E**2) + sum(WH * H**2) with fixed pseudo-random weights ("dense"), or
+# -sum(E**2 + H**2) over a small window as reference examples/learnable_focus.py:121-124.
+ADJOINT_SCENES = {
+    "adjoint_focus2d": dict(
+        grid=dict(shape=(40, 40, 1)),
+        items=[
+            ("periodic",  (S(None), S(None), 0), {}),
+            ("point",     (20, 8, 0), dict(period=14)),
+            ("learnable", (S(10, 30), S(15, 25), S(0, 1)), dict(permittivity=2.5)),
+        ],
+        steps=50, chunks=(50,),
+        loss=dict(kind="window", window=(S(17, 23), 32, S(0, 1))),
+    ),
+    "adjoint_pml3d": dict(
+        grid=dict(shape=(14, 13, 12)),
+        items=[
+            ("pml",       (S(0, 3), S(None), S(None)), {}),
+            ("pml",       (S(None), S(-3, None), S(None)), {}),
+            ("periodic",  (S(None), S(None), 0), {}),
+            ("pml",       (S(-3, None), S(None), S(None)), {}),       # registered after the periodic one
+            ("learnable", (S(4, 10), S(3, 9), S(2, 9)), dict(permittivity=3.0), dict(offdiag_seed=2, offdiag_scale=0.05)),
+            ("learnable", (S(2, 6), S(8, 12), S(5, 11)), dict(permittivity=2.5), dict(offdiag_seed=3, offdiag_scale=0.03)),  # overlaps the first and a PML
+            ("absorbing", (S(8, 12), S(2, 6), S(4, 8)), dict(permittivity=1.8, conductivity=4e4)),   # overlaps the first
+            ("object",    (S(6, 9), S(6, 10), S(0, 3)), dict(permittivity=2.2)),
+            ("point",     (7, 6, 6), dict(period=8)),
+            ("plane",     (S(3, 11), S(2, 11), 10), dict(period=9, polarization="x")),
+        ],
+        steps=24, chunks=(10, 14),     # two consecutive runs chained through the state
+        loss=dict(kind="dense", seed=5),
+    ),
+}
+
+
+def adjoint_loss(scene, grid, xp):
+    """Scalar loss of an adjoint scene from the grid's final fields; ``xp`` is torch."""
+    spec = scene["loss"]
+    if spec["kind"] == "window":
+        w = spec["window"]
+        return -1.0 * xp.sum(xp.sum(grid.E[w] ** 2 + grid.H[w] ** 2, -1))
+    rs = np.random.RandomState(spec["seed"])
+    shape = tuple(grid.E.shape)
+    WE = xp.as_tensor(rs.rand(*shape), dtype=grid.E.dtype, device=grid.E.device)
+    WH = xp.as_tensor(rs.rand(*shape), dtype=grid.E.dtype, device=grid.E.device)
+    return xp.sum(WE * grid.E ** 2) + xp.sum(WH * grid.H ** 2)
+
+
 def _materialise(v):
     if isinstance(v, tuple) and v and v[0] == "randpos":
         return _randpos(*v[1:])
@@ -257,13 +304,14 @@ def build_api(scene, fdtd, grid_factory=None):
         cls = {
             "pml": fdtd.PML, "periodic": fdtd.PeriodicBoundary, "object": fdtd.Object,
             "absorbing": fdtd.AbsorbingObject, "anisotropic": fdtd.AnisotropicObject,
+            "learnable": fdtd.LearnableAnisotropicObject,
             "point": fdtd.PointSource, "line": fdtd.LineSource, "plane": fdtd.PlaneSource,
             "linedet": fdtd.LineDetector, "blockdet": fdtd.BlockDetector,
             "currentdet": fdtd.CurrentDetector,
         }[kind]
         thing = cls(**kw)
         grid[key] = thing
-        if kind == "anisotropic" and extra:
+        if kind in ("anisotropic", "learnable") and extra:
             fill_offdiag(thing, extra)
         made.append((kind, thing, kw, extra))
     return grid, made

@@ -1,0 +1,95 @@
+"""Backward-through-time adjoint kernels against the reference's autograd gradients.
+
+Golden values (tests/golden/adjoint_*.npz) come from the reference's torch backend
+back-propagating the same loss (tests/golden/make_golden_adjoint.py).  Tolerance:
+rel-L2 <= 1e-10 in float64 (reverse-time summation order differs from autograd's),
+<= 2e-4 in float32 against the float64 reference.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fdtd_amd as fdtd
+import scenes
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel_l2(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return np.linalg.norm((got - want).ravel()) / np.linalg.norm(want.ravel())
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("float32", 2e-4)])
+@pytest.mark.parametrize("name", sorted(scenes.ADJOINT_SCENES))
+def test_gradients_match_reference_autograd(name, dtype, tol):
+    fdtd.set_backend(f"hip.{dtype}")
+    scene = scenes.ADJOINT_SCENES[name]
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    grid, made = scenes.build_api(scene, fdtd)
+    for n in scene["chunks"]:
+        grid.run(n, progress_bar=False)
+    assert grid.time_steps_passed == scene["steps"]
+    loss = scenes.adjoint_loss(scene, grid, torch)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel_l2(grid.E.detach().cpu().numpy(), z["E"]) <= (1e-12 if dtype == "float64" else 1e-5)
+    assert abs(loss.item() - float(z["loss"])) <= (1e-11 if dtype == "float64" else 1e-4) * abs(float(z["loss"]))
+    seen = 0
+    for n, (kind, t, _, _) in enumerate(made):
+        if kind == "learnable":
+            g = t.inverse_permittivity.grad
+            assert g is not None and tuple(g.shape) == z[f"grad{n}"].shape
+            err = rel_l2(g.cpu().numpy(), z[f"grad{n}"])
+            assert err <= tol, f"{name}/{dtype}: object {n} gradient rel-L2 {err:.3e}"
+            seen += 1
+    assert seen >= 1
+
+
+def test_gradient_against_finite_differences():
+    """Directional derivative of the loss w.r.t. the learnable tensor and the initial
+    fields, central differences in float64."""
+    fdtd.set_backend("hip.float64")
+    scene = scenes.ADJOINT_SCENES["adjoint_pml3d"]
+    rs = np.random.RandomState(3)
+
+    def run(delta_M, delta_E, eps):
+        grid, made = scenes.build_api(scene, fdtd)
+        obj = [t for k, t, _, _ in made if k == "learnable"][0]
+        with torch.no_grad():
+            obj.inverse_permittivity += eps * delta_M
+        grid.E = (eps * delta_E).clone().requires_grad_(True)
+        E0 = grid.E
+        grid.run(12, progress_bar=False)
+        return scenes.adjoint_loss(scene, grid, torch), obj, E0
+
+    grid0, made0 = scenes.build_api(scene, fdtd)
+    obj0 = [t for k, t, _, _ in made0 if k == "learnable"][0]
+    dM = fdtd.backend.array(rs.randn(*obj0.inverse_permittivity.shape))
+    dE = fdtd.backend.array(1e-2 * rs.randn(*grid0.E.shape))
+    loss, obj, E0 = run(dM, dE, 0.0)
+    loss.backward()
+    analytic = (obj.inverse_permittivity.grad * dM).sum().item() + (E0.grad * dE).sum().item()
+    h = 1e-6
+    with torch.no_grad():
+        lp, _, _ = run(dM, dE, h)
+        lm, _, _ = run(dM, dE, -h)
+    numeric = (lp.item() - lm.item()) / (2 * h)
+    assert abs(analytic - numeric) <= 1e-6 * max(abs(numeric), 1e-30), (analytic, numeric)
+
+
+def test_no_grad_run_leaves_no_graph():
+    fdtd.set_backend("hip.float64")
+    scene = scenes.ADJOINT_SCENES["adjoint_focus2d"]
+    grid, made = scenes.build_api(scene, fdtd)
+    with torch.no_grad():
+        grid.run(5, progress_bar=False)
+    assert grid.E.grad_fn is None and not grid.E.requires_grad
+    grid.run(5, progress_bar=False)
+    assert grid.E.grad_fn is not None
+    with pytest.raises(NotImplementedError):
+        grid.update_E()
