@@ -79,6 +79,7 @@ struct SourceH {
   int64_t n;
   int box[6];
   int64_t* elem = nullptr;    // device: flat element index of (cell, compE)
+  int64_t elem_min = 0, elem_max = -1;
   double* profile = nullptr;  // device
   double amplitude = 0;       // SET_BOX
   int serial = 0;
@@ -378,19 +379,29 @@ double waveform(const SourceH& s, int64_t q) {
   return std::sin(2 * M_PI * (double)q / s.period + s.phase);
 }
 
+// The pieces of a half step that follow the bulk pass, selectable so that a run can
+// interleave plane chunks of the two half steps: boundaries (periodic copies, PMLs
+// registered after a periodic boundary), sources restricted to planes [x0, x1),
+// and the end-of-half-step work (detectors, curl-trace cursor).
+enum { POST_BOUNDARIES = 1, POST_SOURCES = 2, POST_FINISH = 4, POST_ALL = 7 };
+
 template <typename T>
-int post(fdtdhip_plan* p, bool phaseE, int64_t q) {
+int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 = 0, int x1 = -1) {
   T* F = (T*)(phaseE ? p->E : p->H);
   const T* mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
   if (!F || !mat) return fail(-1, "fields not set");
-  if (phaseE && p->trace_cursor >= 0) {  // the E bulk pass of this step filled one trace row
-    ++p->trace_cursor;
+  if (x1 < 0) x1 = p->nx;
+  const int64_t plane3 = (int64_t)p->ny * p->nz * 3;
+  const int64_t elem_lo = x0 * plane3, elem_hi = x1 * plane3;
+  if ((parts & POST_FINISH) && phaseE && p->trace_cursor >= 0) {
+    ++p->trace_cursor;  // the E bulk pass of this step filled one trace row
     for (const ObjH& o : p->objs)
       if (o.trace && p->trace_cursor >= o.trace_capacity) p->trace_cursor = -1;  // traces full
   }
   // boundaries that follow the first periodic one, in list order
   bool seen_periodic = false;
   for (const BoundaryRef& b : p->boundaries) {
+    if (!(parts & POST_BOUNDARIES)) break;
     if (b.kind == 1) {
       seen_periodic = true;
       const int axis = b.idx;
@@ -409,11 +420,14 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q) {
     }
   }
   for (const SourceH& s : p->sources) {
+    if (!(parts & POST_SOURCES)) break;
     const double w = waveform(s, q);
     if (s.kind == FDTDHIP_SRC_ADD_POINTS) {
-      if (!phaseE) continue;
+      if (!phaseE || s.n == 0) continue;
+      if (s.elem_max < elem_lo || s.elem_min >= elem_hi) continue;  // no point in these planes
       hipLaunchKernelGGL((source_add_points<T>), dim3(s.serial ? 1 : blocks_for(s.n, 64)),
-                         dim3(64), 0, p->stream, F, s.elem, s.profile, w, s.n, s.serial);
+                         dim3(64), 0, p->stream, F, s.elem, s.profile, w, s.n, s.serial, elem_lo,
+                         elem_hi);
     } else {
       const int64_t total =
           (int64_t)(s.box[1] - s.box[0]) * (s.box[3] - s.box[2]) * (s.box[5] - s.box[4]);
@@ -424,6 +438,7 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q) {
     }
   }
   for (DetH& d : p->dets) {
+    if (!(parts & POST_FINISH)) break;
     if (d.kind == FDTDHIP_DET_CELLS) {
       int64_t& used = phaseE ? d.usedE : d.usedH;
       char* base = phaseE ? d.outE : d.outH;
@@ -702,6 +717,8 @@ int fdtdhip_plan_add_source(fdtdhip_plan* p, int kind, int compE, int compH, int
           return fail(-1, "source point outside the grid");
       elem[i] = ((((int64_t)cells[3 * i] * p->ny) + cells[3 * i + 1]) * p->nz + cells[3 * i + 2]) * 3 + compE;
       if (!seen.insert(elem[i]).second) s.serial = 1;
+      if (i == 0 || elem[i] < s.elem_min) s.elem_min = elem[i];
+      if (i == 0 || elem[i] > s.elem_max) s.elem_max = elem[i];
     }
     if (n > 0) {
       HIPCHK(hipMalloc((void**)&s.elem, sizeof(int64_t) * (size_t)n));

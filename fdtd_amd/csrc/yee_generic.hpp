@@ -17,9 +17,8 @@ namespace fdtdhip {
 // normal axis a compile-time constant so that the two transverse components
 // u=(AXIS+1)%3, v=(AXIS+2)%3 are static register indices.
 //   dFu, dFv : difference along AXIS of components u and v of the driving field
-//   first    : E half step -> true: accumulate where slab-local index >= 1
-//              H half step -> false: accumulate where slab-local index <= t-2
-//   sign     : +1 for E (E += ...), -1 for H (H -= ...)
+//   phaseE   : E half step: accumulate where the slab-local index is >= 1, F += ...;
+//              H half step: accumulate where it is <= t-2, F -= ...
 template <typename T, int AXIS>
 __device__ __forceinline__ void pml_face(const PmlK<T>& P, int nx, int i, int j, int k, T dFu,
                                          T dFv, bool phaseE, T sc, T f[3], const T m[3]) {
@@ -280,14 +279,16 @@ __global__ void periodic_copy(T* F, int nx, int ny, int nz, int axis, int dst, i
 // `serial` keeps the reference's sequential order when a cell is listed twice.
 template <typename T>
 __global__ void source_add_points(T* F, const int64_t* elem, const double* profile, double w,
-                                  int64_t n, int serial) {
+                                  int64_t n, int serial, int64_t lo, int64_t hi) {
+  // only elements in [lo, hi) (a range of x planes) are touched
   if (serial) {
     if (blockIdx.x == 0 && threadIdx.x == 0)
-      for (int64_t p = 0; p < n; ++p) F[elem[p]] += (T)(profile[p] * w);
+      for (int64_t p = 0; p < n; ++p)
+        if (elem[p] >= lo && elem[p] < hi) F[elem[p]] += (T)(profile[p] * w);
     return;
   }
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n) F[elem[p]] += (T)(profile[p] * w);
+  if (p < n && elem[p] >= lo && elem[p] < hi) F[elem[p]] += (T)(profile[p] * w);
 }
 
 // Hard plane source (reference fdtd/sources.py:519, 525): F[box, comp] = value.

@@ -189,7 +189,41 @@ void calib(size_t stagger) {
   }
 }
 
+// Infinity Cache probe: repeated read / write-then-read of buffers of growing size.
+void mall_probe() {
+  const size_t max_bytes = (size_t)1 << 31;
+  float4 *a, *o;
+  CHECK(hipMalloc(&a, max_bytes));
+  CHECK(hipMalloc(&o, max_bytes));
+  fill<float><<<4096, 256>>>((float*)a, max_bytes / 4, 1, -1.f, 1.f);
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  const size_t sizes_mb[] = {16, 32, 64, 96, 128, 192, 256, 384, 512, 1024, 2048};
+  for (size_t mb : sizes_mb) {
+    const size_t n4 = mb * (1 << 20) / 16;
+    const unsigned grid = (unsigned)((n4 + 255) / 256);
+    float t_read = 0, t_copy = 0, t_wr = 0;
+    for (int mode = 0; mode < 3; ++mode) {
+      for (int r = 0; r < 12; ++r) {
+        CHECK(hipEventRecord(e0, 0));
+        if (mode == 0) stream_read<<<grid, 256>>>(a, o, n4);
+        else if (mode == 1) stream_copy<<<grid, 256>>>(a, o, n4);
+        else { stream_copy<<<grid, 256>>>(a, o, n4); stream_read<<<grid, 256>>>(o, a, n4); }
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 2) (mode == 0 ? t_read : mode == 1 ? t_copy : t_wr) += ms / 10;
+      }
+    }
+    const double b = (double)n4 * 16;
+    printf("mall %5zu MB | re-read %.0f GB/s | copy %.0f GB/s | copy then read-back of the copy %.0f GB/s (3 transfers)\n",
+           mb, b / t_read / 1e6, 2 * b / t_copy / 1e6, 3 * b / t_wr / 1e6);
+  }
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "mall")) { mall_probe(); return 0; }
   if (argc >= 2 && !strcmp(argv[1], "calib")) { calib(argc > 2 ? (size_t)atol(argv[2]) : 0); return 0; }
   if (argc < 6) {
     fprintf(stderr, "usage: kbench nx ny nz f32|f64 steps [pml]\n");
