@@ -225,8 +225,10 @@ class PML(Boundary):
     def _signature(self):
         if not self._active:
             return ("pml-elsewhere", id(self))
+        alt = getattr(self, "_psiE_alt", None)
         return ("pml", id(self), self.axis, self.side, self.thickness,
-                self._psiE.data_ptr(), self._psiH.data_ptr(), self._psiE.dtype)
+                self._psiE.data_ptr(), self._psiH.data_ptr(), self._psiE.dtype,
+                alt.data_ptr() if alt is not None else 0)
 
     def _native_add(self, lib, plan):
         if not self._active:
@@ -240,6 +242,12 @@ class PML(Boundary):
             _lib.doubles(self._bE1d), _lib.doubles(self._cE1d),
             _lib.doubles(self._bH1d), _lib.doubles(self._cH1d),
             self._psiE.data_ptr(), self._psiH.data_ptr()))
+        alt = getattr(self, "_psiE_alt", None)
+        if alt is not None and (alt.shape != self._psiE.shape or alt.dtype != self._psiE.dtype
+                                or alt.device != self._psiE.device):
+            alt = self._psiE_alt = None
+        if alt is not None:
+            _lib.check(lib.fdtdhip_plan_set_pml_step_buffer(plan, self._native_id, alt.data_ptr()))
 
     # ------------------------------------- the reference's attribute names
     def _expand(self, profile, pad_value):

@@ -19,6 +19,7 @@
 #include "yee_generic.hpp"
 #include "yee_tiled.hpp"
 #include "yee_adjoint.hpp"
+#include "yee_step.hpp"
 
 namespace {
 
@@ -55,6 +56,7 @@ struct PmlH {
   void* psiH;
   void *bE, *cE, *bH, *cH;  // device arrays of the plan's element type
   bool fused;               // no periodic boundary precedes it in the list
+  void* psiE_alt = nullptr; // second psiE buffer of the fused full step
   void* lamE = nullptr;     // adjoints of psiE / psiH (differentiable runs)
   void* lamH = nullptr;
 };
@@ -80,6 +82,8 @@ struct SourceH {
   int box[6];
   int64_t* elem = nullptr;    // device: flat element index of (cell, compE)
   int64_t elem_min = 0, elem_max = -1;
+  std::vector<int64_t> elem_host;     // the same lists on the host (fused full step)
+  std::vector<double> profile_host;
   double* profile = nullptr;  // device
   double amplitude = 0;       // SET_BOX
   int serial = 0;
@@ -107,6 +111,8 @@ struct fdtdhip_plan {
   void *E = nullptr, *H = nullptr;
   const void *inv_eps = nullptr, *inv_mu = nullptr;
   const void *H_below = nullptr, *E_above = nullptr;
+  void *E_alt = nullptr, *H_alt = nullptr;  // second field pair of the fused full step
+  bool step_flipped = false;                // an odd number of fused steps has been taken
   std::vector<BoundaryRef> boundaries;
   std::vector<PmlH> pmls;
   std::vector<ObjH> objs;
@@ -115,6 +121,9 @@ struct fdtdhip_plan {
   void* obj_table = nullptr;  // device ObjK<T>[]
   size_t obj_table_bytes = 0;
   bool obj_dirty = false;
+  // device tables of PML descriptors, one per use (see PmlTab); rebuilt when dirty
+  void* pml_tables = nullptr;
+  bool pml_dirty = true;
   int64_t trace_cursor = -1;  // row of the curl traces the next E half step writes; -1: no traces
   std::vector<void*> owned;   // device allocations released by reset/destroy
   // optional kernel timing (fdtdhip_plan_enable_timing)
@@ -140,6 +149,8 @@ int release_tables(fdtdhip_plan* p) {
   p->obj_table = nullptr;
   p->obj_table_bytes = 0;
   p->trace_cursor = -1;
+  p->pml_dirty = true;
+  p->step_flipped = false;
   p->boundaries.clear();
   p->pmls.clear();
   p->objs.clear();
@@ -196,10 +207,53 @@ int sync_obj_table(fdtdhip_plan* p) {
   return 0;
 }
 
+// Which PML descriptor table a kernel reads: the two half steps in place, the E half
+// of the fused full step in its two directions (first -> second psi_E buffer and
+// back), and the adjoint half steps (psi -> adjoint arrays).
+enum PmlTab { TAB_E = 0, TAB_H, TAB_E_AB, TAB_E_BA, TAB_ADJ_E, TAB_ADJ_H, TAB_COUNT };
+
+template <typename T>
+PmlK<T> make_pmlk(const fdtdhip_plan* p, const PmlH& h, bool phaseE);
+
+template <typename T>
+int sync_pml_tables(fdtdhip_plan* p) {
+  if (!p->pml_dirty) return 0;
+  const size_t bytes = sizeof(PmlK<T>) * MAX_PML * TAB_COUNT;
+  if (!p->pml_tables) HIPCHK(hipMalloc(&p->pml_tables, bytes));
+  std::vector<PmlK<T>> host(MAX_PML * TAB_COUNT);
+  for (size_t i = 0; i < p->pmls.size(); ++i) {
+    const PmlH& h = p->pmls[i];
+    PmlK<T> e = make_pmlk<T>(p, h, true), hh = make_pmlk<T>(p, h, false);
+    host[TAB_E * MAX_PML + i] = e;
+    host[TAB_H * MAX_PML + i] = hh;
+    PmlK<T> ab = e, ba = e;
+    ab.psi_out = (T*)h.psiE_alt;
+    ba.psi = (T*)h.psiE_alt;
+    ba.psi_out = (T*)h.psiE;
+    host[TAB_E_AB * MAX_PML + i] = ab;
+    host[TAB_E_BA * MAX_PML + i] = ba;
+    PmlK<T> ae = e, ah = hh;
+    ae.psi = ae.psi_out = (T*)h.lamE;
+    ah.psi = ah.psi_out = (T*)h.lamH;
+    host[TAB_ADJ_E * MAX_PML + i] = ae;
+    host[TAB_ADJ_H * MAX_PML + i] = ah;
+  }
+  HIPCHK(hipMemcpyAsync(p->pml_tables, host.data(), bytes, hipMemcpyHostToDevice, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  p->pml_dirty = false;
+  return 0;
+}
+
+template <typename T>
+const PmlK<T>* pml_table(const fdtdhip_plan* p, int which) {
+  return (const PmlK<T>*)p->pml_tables + which * MAX_PML;
+}
+
 template <typename T>
 PmlK<T> make_pmlk(const fdtdhip_plan* p, const PmlH& h, bool phaseE) {
   PmlK<T> k;
   k.psi = (T*)(phaseE ? h.psiE : h.psiH);
+  k.psi_out = k.psi;
   k.b = (const T*)(phaseE ? h.bE : h.bH);
   k.c = (const T*)(phaseE ? h.cE : h.cH);
   k.axis = h.axis;
@@ -304,7 +358,8 @@ int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
   a.nobj = phaseE ? (int)p->objs.size() : 0;
   a.obj = (const ObjK<T>*)p->obj_table;
   a.trace_step = phaseE ? p->trace_cursor : -1;
-  for (int i = 0; i < a.npml; ++i) a.pml[i] = make_pmlk<T>(p, p->pmls[i], phaseE);
+  if (int rc = sync_pml_tables<T>(p)) return rc;
+  a.pml = pml_table<T>(p, phaseE ? TAB_E : TAB_H);
 
   const bool pml = a.npml > 0, obj = a.nobj > 0;
   const int64_t plane = (int64_t)p->ny * p->nz;
@@ -510,7 +565,7 @@ int adjoint_half(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
     } else {
       const PmlH& h = p->pmls[br.idx];
       PmlK<T> k = make_pmlk<T>(p, h, phaseE);
-      k.psi = (T*)(phaseE ? h.lamE : h.lamH);
+      k.psi = k.psi_out = (T*)(phaseE ? h.lamE : h.lamH);
       if (!k.psi) return fail(-1, "PML adjoint arrays not set");
       const int64_t slab = (int64_t)(h.axis == 0 ? h.t : p->nx) * k.sy * k.sz;
       hipLaunchKernelGGL((adj_pml_apply_slab<T>), dim3(blocks_for(slab)), dim3(256), 0, p->stream,
@@ -525,11 +580,10 @@ int adjoint_half(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
   a.nobj = phaseE ? (int)p->objs.size() : 0;
   a.obj = (const ObjK<T>*)p->obj_table;
   a.trace_step = phaseE ? p->trace_cursor : -1;
-  for (int i = 0; i < a.npml; ++i) {
-    a.pml[i] = make_pmlk<T>(p, p->pmls[i], phaseE);
-    a.pml[i].psi = (T*)(phaseE ? p->pmls[i].lamE : p->pmls[i].lamH);
-    if (!a.pml[i].psi) return fail(-1, "PML adjoint arrays not set");
-  }
+  for (const PmlH& h : p->pmls)
+    if (!(phaseE ? h.lamE : h.lamH)) return fail(-1, "PML adjoint arrays not set");
+  if (int rc = sync_pml_tables<T>(p)) return rc;
+  a.pml = pml_table<T>(p, phaseE ? TAB_ADJ_E : TAB_ADJ_H);
   const dim3 grid(blocks_for(p->cells())), block(256);
   if (phaseE) {
     hipLaunchKernelGGL((adj_E_cells<T>), grid, block, 0, p->stream, a);
@@ -554,6 +608,124 @@ int adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH, void* w
   }
   p->trace_cursor = -1;
   return 0;
+}
+
+// ---- fused full step (yee_step.hpp) -------------------------------------------------
+// Usable when nothing has to happen between the two half steps that the fused
+// kernel cannot do itself: no periodic boundary, no hard plane source, no x-slab
+// halo, no curl trace being recorded, at most MAX_STEP_SOURCES additive source points
+// without repeated cells, and the caller has provided the second buffers.
+constexpr int64_t FUSED_AUTO_MAX_CELLS = 1 << 19;
+
+bool fused_eligible(const fdtdhip_plan* p) {
+  // FDTDHIP_FUSED=0 never, =1 whenever possible; by default only for grids small
+  // enough that launch count, not memory traffic, sets the step time (the fused
+  // kernel reads more through L1 than the two half-step kernels and is slower on
+  // large grids: 512^3 fp32 3.2 ms against 2.2 ms).
+  static const int mode = [] {
+    const char* e = getenv("FDTDHIP_FUSED");
+    return e ? (atoi(e) ? 1 : 0) : -1;
+  }();
+  if (mode == 0 || !p->E_alt || !p->H_alt) return false;
+  if (mode < 0 && (int64_t)p->nx * p->ny * p->nz > FUSED_AUTO_MAX_CELLS) return false;
+  if (p->H_below || p->E_above || p->trace_cursor >= 0) return false;
+  if (p->nx > 65535 || (int64_t)p->ny * p->nz >= (1ll << 30)) return false;
+  for (const BoundaryRef& b : p->boundaries)
+    if (b.kind == 1) return false;
+  for (const PmlH& h : p->pmls)
+    if (!h.psiE_alt) return false;
+  int64_t points = 0;
+  for (const SourceH& s : p->sources) {
+    if (s.kind != FDTDHIP_SRC_ADD_POINTS || s.serial) return false;
+    points += s.n;
+  }
+  return points <= MAX_STEP_SOURCES;
+}
+
+template <typename T>
+int fused_step(fdtdhip_plan* p, int64_t q) {
+  if (int rc = sync_obj_table<T>(p)) return rc;
+  StepArgs<T> a;
+  for (int phase = 0; phase < 2; ++phase) {
+    const bool phaseE = phase == 0;
+    BulkArgs<T>& b = phaseE ? a.e : a.h;
+    b.F = (T*)(phaseE ? p->E : p->H);
+    b.G = (const T*)(phaseE ? p->H : p->E);
+    b.mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
+    b.ghost = nullptr;
+    b.nx = p->nx; b.ny = p->ny; b.nz = p->nz;
+    b.x0 = 0; b.x1 = p->nx;
+    b.sc = (T)p->sc;
+    b.npml = (int)p->pmls.size();
+    b.nobj = phaseE ? (int)p->objs.size() : 0;
+    b.obj = (const ObjK<T>*)p->obj_table;
+    b.trace_step = -1;
+  }
+  if (int rc = sync_pml_tables<T>(p)) return rc;
+  // p->step_flipped: the state currently lives in the second buffers
+  a.e.pml = pml_table<T>(p, p->step_flipped ? TAB_E_BA : TAB_E_AB);
+  a.h.pml = pml_table<T>(p, TAB_H);
+  a.E1 = (T*)p->E_alt;
+  a.H1 = (T*)p->H_alt;
+  a.nsrc = 0;
+  for (const SourceH& s : p->sources) {
+    const double w = waveform(s, q);
+    for (int64_t i = 0; i < s.n; ++i) {
+      a.src_elem[a.nsrc] = s.elem_host[i];
+      a.src_value[a.nsrc] = (T)(s.profile_host[i] * w);
+      ++a.nsrc;
+    }
+  }
+  const int64_t plane = (int64_t)p->ny * p->nz;
+  const dim3 grid((unsigned)((plane + 255) / 256), p->nx, 1), block(256);
+  const bool pml = a.e.npml > 0, obj = a.e.nobj > 0;
+  // one-lane-per-cell form unless FDTDHIP_STEP=march asks for the marching form
+  static const int step_form = [] {
+    const char* e = getenv("FDTDHIP_STEP");
+    return e ? (std::string(e) == "simple" ? 1 : 2) : 0;
+  }();
+  static const int xchunk_env = [] {
+    const char* e = getenv("FDTDHIP_XCHUNK");
+    return e ? atoi(e) : 0;
+  }();
+  const bool march = step_form == 2;
+  size_t slot = 0;
+  if (p->timing) {
+    if (p->ev_phase.size() >= 2048)
+      if (int rc = drain_timing(p)) return rc;
+    slot = p->ev_phase.size();
+    if (slot >= p->ev_pool.size()) {
+      hipEvent_t e0, e1;
+      HIPCHK(hipEventCreate(&e0));
+      HIPCHK(hipEventCreate(&e1));
+      p->ev_pool.push_back({e0, e1});
+    }
+    HIPCHK(hipEventRecord(p->ev_pool[slot].first, p->stream));
+  }
+  if (march) {
+    constexpr int NW = 8;
+    const int xchunk = xchunk_env > 0 ? xchunk_env : 32;
+    const dim3 mgrid((p->nz + 62) / 63, (p->ny + NW - 2) / (NW - 1), (p->nx + xchunk - 1) / xchunk);
+    const dim3 mblock(NW * 64);
+    if (pml && obj) hipLaunchKernelGGL((step_march<T, NW, true, true>), mgrid, mblock, 0, p->stream, a, xchunk);
+    else if (pml) hipLaunchKernelGGL((step_march<T, NW, true, false>), mgrid, mblock, 0, p->stream, a, xchunk);
+    else if (obj) hipLaunchKernelGGL((step_march<T, NW, false, true>), mgrid, mblock, 0, p->stream, a, xchunk);
+    else hipLaunchKernelGGL((step_march<T, NW, false, false>), mgrid, mblock, 0, p->stream, a, xchunk);
+  } else if (pml && obj) hipLaunchKernelGGL((step_fused<T, true, true>), grid, block, 0, p->stream, a);
+  else if (pml) hipLaunchKernelGGL((step_fused<T, true, false>), grid, block, 0, p->stream, a);
+  else if (obj) hipLaunchKernelGGL((step_fused<T, false, true>), grid, block, 0, p->stream, a);
+  else hipLaunchKernelGGL((step_fused<T, false, false>), grid, block, 0, p->stream, a);
+  HIPCHK(hipGetLastError());
+  if (p->timing) {
+    HIPCHK(hipEventRecord(p->ev_pool[slot].second, p->stream));
+    p->ev_phase.push_back(1);
+  }
+  // the second buffers now hold the current state
+  std::swap(p->E, p->E_alt);
+  std::swap(p->H, p->H_alt);
+  p->step_flipped = !p->step_flipped;  // psi_E follows through the two fused PML tables
+  if (int rc = post<T>(p, true, q, POST_FINISH)) return rc;
+  return post<T>(p, false, q, POST_FINISH);
 }
 
 #define DISPATCH(p, call_f32, call_f64) ((p)->dtype == FDTDHIP_F32 ? (call_f32) : (call_f64))
@@ -600,6 +772,7 @@ int fdtdhip_plan_destroy(fdtdhip_plan* p) {
     DeviceGuard g(p->device);
     (void)hipStreamSynchronize(p->stream);
     release_tables(p);
+    if (p->pml_tables) (void)hipFree(p->pml_tables);
     for (auto& e : p->ev_pool) {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
@@ -620,6 +793,21 @@ int fdtdhip_plan_set_fields(fdtdhip_plan* p, void* E, void* H, const void* inv_e
   if (!p) return fail(-1, "null plan");
   if (!E || !H || !inv_eps || !inv_mu) return fail(-1, "null field pointer");
   p->E = E; p->H = H; p->inv_eps = inv_eps; p->inv_mu = inv_mu;
+  return 0;
+}
+
+int fdtdhip_plan_set_step_buffers(fdtdhip_plan* p, void* E_alt, void* H_alt) {
+  if (!p) return fail(-1, "null plan");
+  p->E_alt = E_alt;
+  p->H_alt = H_alt;
+  return 0;
+}
+
+int fdtdhip_plan_set_pml_step_buffer(fdtdhip_plan* p, int id, void* psiE_alt) {
+  if (!p) return fail(-1, "null plan");
+  if (id < 0 || id >= (int)p->pmls.size()) return fail(-1, "unknown PML id");
+  p->pmls[id].psiE_alt = psiE_alt;
+  p->pml_dirty = true;
   return 0;
 }
 
@@ -657,6 +845,7 @@ int fdtdhip_plan_add_pml(fdtdhip_plan* p, int axis, int side, int t, const doubl
       return rc;
   }
   p->pmls.push_back(h);
+  p->pml_dirty = true;
   p->boundaries.push_back({0, (int)p->pmls.size() - 1});
   return (int)p->pmls.size() - 1;
 }
@@ -720,6 +909,8 @@ int fdtdhip_plan_add_source(fdtdhip_plan* p, int kind, int compE, int compH, int
       if (i == 0 || elem[i] < s.elem_min) s.elem_min = elem[i];
       if (i == 0 || elem[i] > s.elem_max) s.elem_max = elem[i];
     }
+    s.elem_host = elem;
+    s.profile_host.assign(profile, profile + n);
     if (n > 0) {
       HIPCHK(hipMalloc((void**)&s.elem, sizeof(int64_t) * (size_t)n));
       p->owned.push_back(s.elem);
@@ -814,7 +1005,18 @@ int fdtdhip_update_H(fdtdhip_plan* p, int64_t q) {
 
 int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
   if (!p) return fail(-1, "null plan");
-  for (int64_t s = 0; s < nsteps; ++s) {
+  int64_t s = 0;
+  if (fused_eligible(p)) {
+    // pairs of fused steps: first -> second buffers and back, so that the state ends
+    // where the caller's tensors are; an odd last step runs as two half steps
+    DeviceGuard g(p->device);
+    for (; s + 1 < nsteps; s += 2)
+      for (int k = 0; k < 2; ++k) {
+        const int rc = DISPATCH(p, fused_step<float>(p, q0 + s + k), fused_step<double>(p, q0 + s + k));
+        if (rc) return rc;
+      }
+  }
+  for (; s < nsteps; ++s) {
     if (int rc = fdtdhip_update_E(p, q0 + s)) return rc;
     if (int rc = fdtdhip_update_H(p, q0 + s)) return rc;
   }
@@ -848,6 +1050,7 @@ int fdtdhip_plan_set_pml_adjoint(fdtdhip_plan* p, int id, void* lam_psiE, void* 
   if (id < 0 || id >= (int)p->pmls.size()) return fail(-1, "unknown PML id");
   p->pmls[id].lamE = lam_psiE;
   p->pmls[id].lamH = lam_psiH;
+  p->pml_dirty = true;
   return 0;
 }
 

@@ -17,6 +17,8 @@ constexpr int MAX_PML = 6;  // one per face: the reference refuses a second boun
 template <typename T>
 struct PmlK {
   T* psi;       // (2, slab cells): [0] -> component u=(axis+1)%3, [1] -> component v=(axis+2)%3
+  T* psi_out;   // where the advanced memory variables go: `psi` itself, or the second
+                // buffer of a fused full step (neighbour lanes still read the old values)
   const T* b;   // (t) decay of the memory variable along the normal axis
   const T* c;   // (t) gain of the field difference along the normal axis
   int axis;     // normal axis
@@ -55,7 +57,7 @@ struct BulkArgs {
   int nobj;
   const ObjK<T>* obj;
   int64_t trace_step;  // row of the objects' curl traces to write (forward) / read (adjoint); -1: none
-  PmlK<T> pml[MAX_PML];
+  const PmlK<T>* pml;  // device table of npml descriptors (read with scalar loads, one at a time)
 };
 
 // Arguments of the adjoint (reverse-time) half-step kernels.  For the adjoint of
@@ -72,7 +74,7 @@ struct AdjArgs {
   int nobj;
   const ObjK<T>* obj;
   int64_t trace_step;
-  PmlK<T> pml[MAX_PML];  // psi -> adjoint of the memory variables
+  const PmlK<T>* pml;  // device table; psi -> adjoint of the memory variables
 };
 
 }  // namespace fdtdhip

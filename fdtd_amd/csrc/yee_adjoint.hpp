@@ -67,10 +67,8 @@ __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
   T G[6] = {0, 0, 0, 0, 0, 0};
 
   // PML corrections and memory variables (they act on the final E of the half step)
-#pragma unroll
-  for (int p = MAX_PML - 1; p >= 0; --p) {
-    if (p >= a.npml) continue;
-    const PmlK<T>& P = a.pml[p];
+  for (int p = a.npml - 1; p >= 0; --p) {
+    const PmlK<T> P = a.pml[p];
     if (P.axis == 0) adj_pml_face<T, 0>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WX_Y], G[WX_Z]);
     else if (P.axis == 1) adj_pml_face<T, 1>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WY_Z], G[WY_X]);
     else adj_pml_face<T, 2>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WZ_X], G[WZ_Y]);
@@ -146,10 +144,8 @@ __global__ __launch_bounds__(256) void adj_H_cells(AdjArgs<T> a) {
   const T lam[3] = {a.lamF[c3], a.lamF[c3 + 1], a.lamF[c3 + 2]};
   const T m[3] = {a.mat[c3], a.mat[c3 + 1], a.mat[c3 + 2]};
   T G[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int p = MAX_PML - 1; p >= 0; --p) {
-    if (p >= a.npml) continue;
-    const PmlK<T>& P = a.pml[p];
+  for (int p = a.npml - 1; p >= 0; --p) {
+    const PmlK<T> P = a.pml[p];
     if (P.axis == 0) adj_pml_face<T, 0>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WX_Y], G[WX_Z]);
     else if (P.axis == 1) adj_pml_face<T, 1>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WY_Z], G[WY_X]);
     else adj_pml_face<T, 2>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WZ_X], G[WZ_Y]);

@@ -21,7 +21,8 @@ namespace fdtdhip {
 //              H half step: accumulate where it is <= t-2, F -= ...
 template <typename T, int AXIS>
 __device__ __forceinline__ void pml_face(const PmlK<T>& P, int nx, int i, int j, int k, T dFu,
-                                         T dFv, bool phaseE, T sc, T f[3], const T m[3]) {
+                                         T dFv, bool phaseE, T sc, T f[3], const T m[3],
+                                         bool store) {
   constexpr int u = (AXIS + 1) % 3, v = (AXIS + 2) % 3;
   const int coord = AXIS == 0 ? i : (AXIS == 1 ? j : k);
   const int l = coord - P.lo;
@@ -32,8 +33,10 @@ __device__ __forceinline__ void pml_face(const PmlK<T>& P, int nx, int i, int j,
   const T b = P.b[l], cc = P.c[l];
   T p0 = P.psi[s] * b, p1 = P.psi[slab + s] * b;
   if (phaseE ? (l >= 1) : (l <= P.t - 2)) { p0 += dFv * cc; p1 += dFu * cc; }
-  P.psi[s] = p0;
-  P.psi[slab + s] = p1;
+  if (store) {
+    P.psi_out[s] = p0;
+    P.psi_out[slab + s] = p1;
+  }
   if (P.fused) {
     if (phaseE) {
       f[u] += (sc * m[u]) * (-p0);
@@ -48,12 +51,12 @@ __device__ __forceinline__ void pml_face(const PmlK<T>& P, int nx, int i, int j,
 template <typename T>
 struct Diffs;
 
-// All PML faces of the plan, in registration order.  The loop is unrolled over
-// the six possible slots so that the descriptors are read from the kernel
-// argument segment at fixed offsets (scalar loads, no private-memory copy).
+// All PML faces of the plan, in registration order.  The descriptors live in a small
+// device table read at wave-uniform addresses (scalar loads), one face at a time, so
+// that the loop costs no vector registers.
 template <typename T, bool PHASE_E>
 __device__ __forceinline__ void pml_all(const BulkArgs<T>& a, int i, int j, int k,
-                                        const Diffs<T>& d, T f[3], const T m[3]);
+                                        const Diffs<T>& d, T f[3], const T m[3], bool store);
 
 // ---------------------------------------------------------------------------
 // E half step: PML memory update (reference fdtd/boundaries.py:422-448),
@@ -68,23 +71,24 @@ struct Diffs {
 
 template <typename T, bool PHASE_E>
 __device__ __forceinline__ void pml_all(const BulkArgs<T>& a, int i, int j, int k,
-                                        const Diffs<T>& d, T f[3], const T m[3]) {
-#pragma unroll
-  for (int p = 0; p < MAX_PML; ++p) {
-    if (p >= a.npml) break;
-    const PmlK<T>& P = a.pml[p];
-    if (P.axis == 0) pml_face<T, 0>(P, a.nx, i, j, k, d.x_y, d.x_z, PHASE_E, a.sc, f, m);
-    else if (P.axis == 1) pml_face<T, 1>(P, a.nx, i, j, k, d.y_z, d.y_x, PHASE_E, a.sc, f, m);
-    else pml_face<T, 2>(P, a.nx, i, j, k, d.z_x, d.z_y, PHASE_E, a.sc, f, m);
+                                        const Diffs<T>& d, T f[3], const T m[3], bool store) {
+  for (int p = 0; p < a.npml; ++p) {
+    const PmlK<T> P = a.pml[p];
+    if (P.axis == 0) pml_face<T, 0>(P, a.nx, i, j, k, d.x_y, d.x_z, PHASE_E, a.sc, f, m, store);
+    else if (P.axis == 1) pml_face<T, 1>(P, a.nx, i, j, k, d.y_z, d.y_x, PHASE_E, a.sc, f, m, store);
+    else pml_face<T, 2>(P, a.nx, i, j, k, d.z_x, d.z_y, PHASE_E, a.sc, f, m, store);
   }
 }
 
 // Everything of the E half step that follows the neighbour differences, for one
 // cell: curl, grid update, objects in registration order, PML memory update
 // and correction.  `e` holds the cell's E on entry and the new E on return.
+// store = false evaluates the cell without side effects (no memory-variable or trace
+// writes): used when a lane re-derives a neighbour's new E in the fused full step.
 template <typename T, bool HAS_PML, bool HAS_OBJ>
 __device__ __forceinline__ void finish_E(const BulkArgs<T>& a, int i, int j, int k,
-                                         const Diffs<T>& d, T e[3], const T m[3]) {
+                                         const Diffs<T>& d, T e[3], const T m[3],
+                                         bool store = true) {
   T cu[3];
   cu[0] = d.y_z - d.z_y;
   cu[1] = d.z_x - d.x_z;
@@ -109,7 +113,7 @@ __device__ __forceinline__ void finish_E(const BulkArgs<T>& a, int i, int j, int
           e[c] += ((a.sc * O.inv[oc * 3 + c]) * cu[c]) / (T(1) + f);
         }
       } else {
-        if (O.trace && a.trace_step >= 0) {  // differentiable run: keep the curl for the adjoint
+        if (store && O.trace && a.trace_step >= 0) {  // differentiable run: keep the curl
           const int64_t box =
               (int64_t)(O.x1 - O.x0) * (O.y1 - O.y0) * (O.z1 - O.z0);
           T* tr = O.trace + (a.trace_step * box + oc) * 3;
@@ -127,13 +131,14 @@ __device__ __forceinline__ void finish_E(const BulkArgs<T>& a, int i, int j, int
     }
   }
 
-  if (HAS_PML) pml_all<T, true>(a, i, j, k, d, e, m);
+  if (HAS_PML) pml_all<T, true>(a, i, j, k, d, e, m, store);
 }
 
 // Same for the H half step (no objects: reference fdtd/objects.py:128-134).
 template <typename T, bool HAS_PML>
 __device__ __forceinline__ void finish_H(const BulkArgs<T>& a, int i, int j, int k,
-                                         const Diffs<T>& d, T h[3], const T m[3]) {
+                                         const Diffs<T>& d, T h[3], const T m[3],
+                                         bool store = true) {
   T cu[3];
   cu[0] = d.y_z - d.z_y;
   cu[1] = d.z_x - d.x_z;
@@ -141,7 +146,7 @@ __device__ __forceinline__ void finish_H(const BulkArgs<T>& a, int i, int j, int
 #pragma unroll
   for (int c = 0; c < 3; ++c) h[c] -= (a.sc * m[c]) * cu[c];
 
-  if (HAS_PML) pml_all<T, false>(a, i, j, k, d, h, m);
+  if (HAS_PML) pml_all<T, false>(a, i, j, k, d, h, m, store);
 }
 
 // Block index -> block of work.  With BAND, the 8 XCDs (blocks are dealt to them

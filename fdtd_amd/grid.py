@@ -268,6 +268,12 @@ class Grid:
         _lib.check(lib.fdtdhip_plan_set_stream(self._plan, _stream_ptr(bd.device)))
         _lib.check(lib.fdtdhip_plan_set_fields(
             self._plan, E.data_ptr(), H.data_ptr(), ie.data_ptr(), im.data_ptr()))
+        alt = getattr(self, "_step_buffers", None)
+        if alt is not None and (alt[0].shape != E.shape or alt[0].dtype != E.dtype
+                                or alt[0].device != E.device):
+            alt = self._step_buffers = None
+        _lib.check(lib.fdtdhip_plan_set_step_buffers(
+            self._plan, alt[0].data_ptr() if alt else None, alt[1].data_ptr() if alt else None))
         lo, hi = self._halo
         _lib.check(lib.fdtdhip_plan_set_halo(
             self._plan, lo.data_ptr() if lo is not None else None,
@@ -323,6 +329,8 @@ class Grid:
         if not bd.staging and autograd.needs_grad(self):
             autograd.differentiable_advance(self, n)
             return
+        if n >= 2:
+            self._provide_step_buffers()
         lib = self._ensure_plan()
         for det in self.detectors:
             det._reserve(lib, self._plan, n, n)
@@ -330,6 +338,27 @@ class Grid:
         for det in self.detectors:
             det._commit(n, n)
         self.time_steps_passed += n
+
+    def _provide_step_buffers(self):
+        """Second E/H (and PML psi_E) buffers that let ``run`` use the fused full-step
+        kernel; allocated once, and only for scenes the native library can fuse (no
+        periodic boundary, no plane source, few additive source points)."""
+        if getattr(self, "_step_buffers", None) is not None or self.Nx != self.Nx_global:
+            return
+        points = 0
+        for b in self.boundaries:
+            if not hasattr(b, "thickness"):
+                return
+        for s in self.sources:
+            if not hasattr(s, "_wave_args"):
+                return
+            points += len(s.x) if isinstance(s.x, list) else 1
+        if points > 8:
+            return
+        self._step_buffers = (torch.empty_like(self.E.detach()), torch.empty_like(self.H.detach()))
+        for b in self.boundaries:
+            if b._active and getattr(b, "_psiE_alt", None) is None:
+                b._psiE_alt = torch.empty_like(b._psiE.detach())
 
     def run(self, total_time: Number, progress_bar: bool = True):
         """Advance by ``total_time`` (int: steps, float: seconds), reference fdtd/grid.py:250-265.

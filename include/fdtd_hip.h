@@ -156,6 +156,16 @@ int fdtdhip_update_E_post(fdtdhip_plan* plan, int64_t q);
 int fdtdhip_update_H_bulk(fdtdhip_plan* plan, int x0, int x1);
 int fdtdhip_update_H_post(fdtdhip_plan* plan, int64_t q);
 
+/* Second buffers for the fused full step (no reference counterpart: the reference
+ * always runs the two half steps as separate passes, fdtd/grid.py:267-273).  When
+ * E_alt / H_alt (shaped like E / H) and, for every PML, psiE_alt (shaped like psiE)
+ * are provided and nothing has to happen between the half steps (no periodic
+ * boundary, no plane source, no halo), fdtdhip_run advances pairs of steps with one
+ * kernel per step, first -> second buffers and back; after the call the state is
+ * in the first buffers again.  Contents of the second buffers are scratch. */
+int fdtdhip_plan_set_step_buffers(fdtdhip_plan* plan, void* E_alt, void* H_alt);
+int fdtdhip_plan_set_pml_step_buffer(fdtdhip_plan* plan, int id, void* psiE_alt);
+
 /* nsteps full steps starting at time index q0 (reference fdtd/grid.py:250-273). */
 int fdtdhip_run(fdtdhip_plan* plan, int64_t q0, int64_t nsteps);
 

@@ -140,3 +140,20 @@ def test_user_mutation_between_half_steps_and_rebinding():
     o.inverse_permittivity *= 0.5
     g.run(7, progress_bar=False); o.run(7)
     assert rel_l2(host(g.E), o.E) <= 1e-12 and rel_l2(host(g.H), o.H) <= 1e-12
+
+
+@pytest.mark.parametrize("name", ["pml3d", "objects3d", "c1_readme", "detectors"])
+def test_run_and_half_steps_agree_bitwise(name):
+    """``run(n)`` may take whole steps in one fused kernel where the scene allows it;
+    ``update_E``/``update_H`` never do.  Both orders of evaluation round identically."""
+    fdtd.set_backend("hip.float64")
+    scene = scenes.SCENES[name]
+    a, _ = scenes.build_api(scene, fdtd)
+    b, _ = scenes.build_api(scene, fdtd)
+    a.run(scene["steps"], progress_bar=False)
+    for _ in range(scene["steps"]):
+        b.update_E()
+        b.update_H()
+        b.time_steps_passed += 1
+    torch.cuda.synchronize()
+    assert np.array_equal(host(a.E), host(b.E)) and np.array_equal(host(a.H), host(b.H))

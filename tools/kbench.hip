@@ -58,6 +58,13 @@ void run(int nx, int ny, int nz, int steps, int t) {
   const int dtype = sizeof(T) == 4 ? FDTDHIP_F32 : FDTDHIP_F64;
   LIB(fdtdhip_plan_create(&plan, nx, ny, nz, dtype, 0.99 / 1.7320508075688772, 0));
   LIB(fdtdhip_plan_set_fields(plan, E, H, ie, im));
+  const bool fused = getenv("KB_FUSED") && atoi(getenv("KB_FUSED"));
+  if (fused) {
+    T *E2, *H2;
+    CHECK(hipMalloc(&E2, n * sizeof(T)));
+    CHECK(hipMalloc(&H2, n * sizeof(T)));
+    LIB(fdtdhip_plan_set_step_buffers(plan, E2, H2));
+  }
   std::vector<void*> psis;
   if (t > 0) {
     std::vector<double> b(t, 0.9), c(t, -0.05);
@@ -72,17 +79,23 @@ void run(int nx, int ny, int nz, int steps, int t) {
         CHECK(hipMemset(ph, 0, slab * sizeof(T)));
         psis.push_back(pe);
         psis.push_back(ph);
-        LIB(fdtdhip_plan_add_pml(plan, axis, side, t, b.data(), c.data(), b.data(), c.data(), pe, ph));
+        const int id = fdtdhip_plan_add_pml(plan, axis, side, t, b.data(), c.data(), b.data(), c.data(), pe, ph);
+        LIB(id);
+        if (fused) {
+          void* pa;
+          CHECK(hipMalloc(&pa, slab * sizeof(T)));
+          LIB(fdtdhip_plan_set_pml_step_buffer(plan, id, pa));
+        }
       }
   }
-  LIB(fdtdhip_run(plan, 0, 3));
+  LIB(fdtdhip_run(plan, 0, 4));
   CHECK(hipDeviceSynchronize());
   LIB(fdtdhip_plan_enable_timing(plan, 1));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
   CHECK(hipEventRecord(e0, 0));
-  LIB(fdtdhip_run(plan, 3, steps));
+  LIB(fdtdhip_run(plan, 4, steps));
   CHECK(hipEventRecord(e1, 0));
   CHECK(hipEventSynchronize(e1));
   float wall;
@@ -93,11 +106,11 @@ void run(int nx, int ny, int nz, int steps, int t) {
   const double cells = (double)nx * ny * nz;
   const double bytes_half = cells * 12 * sizeof(T);
   const char* strat = getenv("FDTDHIP_BULK");
-  const char* xc = getenv("FDTDHIP_XCHUNK");
-  printf("%-8s xchunk=%-4s %dx%dx%d %s pml=%d | E %.4f ms %.0f GB/s | H %.4f ms %.0f GB/s | step %.4f ms "
+  if (nH == 0) { nH = 1; msH = 0; }
+  printf("%-8s fused=%d %dx%dx%d %s pml=%d | E %.4f ms %.0f GB/s | H %.4f ms %.0f GB/s | step %.4f ms "
          "%.2f Gcells/s (%.0f GB/s algorithmic)\n",
-         strat ? strat : "default", xc ? xc : "-", nx, ny, nz, sizeof(T) == 4 ? "f32" : "f64", t,
-         msE / nE, bytes_half / (msE / nE) / 1e6, msH / nH, bytes_half / (msH / nH) / 1e6,
+         strat ? strat : "default", (int)fused, nx, ny, nz, sizeof(T) == 4 ? "f32" : "f64", t,
+         msE / nE, bytes_half / (msE / nE) / 1e6, msH / nH, msH > 0 ? bytes_half / (msH / nH) / 1e6 : 0.0,
          wall / steps, cells * steps / wall / 1e6, 2 * bytes_half * steps / wall / 1e6);
   LIB(fdtdhip_plan_destroy(plan));
 }
