@@ -15,6 +15,13 @@ Workloads (all synthetic, fields start at zero, a point source drives them):
 With --gpus N > 1 the grid is N slabs of the single-GPU size along x (weak
 scaling), one process per GPU, halo planes exchanged over RCCL.
 
+Materials: the grids are homogeneous outside their objects, as the reference creates
+them, and the library then passes the material arrays to its kernels as constants
+(it proves this with a scan whenever the arrays change).  `roofline` counts only the
+bytes the kernels then have to move.  --materials arrays turns the feature off (every
+kernel reads both material arrays); --also-arrays adds that measurement to the line as
+`array_materials`.
+
 Extra objects in the JSON line:
   roofline      achieved algorithmic GB/s of the bulk kernels from HIP-event
                 timings taken inside the timed region, against the 8 TB/s HBM peak
@@ -104,8 +111,41 @@ def build_workload(fdtd, name, n_slabs=1, rank=0):
         for f in (grid.E, grid.H):
             f.uniform_(-1e-3, 1e-3, generator=gen)
     cells = shape[0] * shape[1] * shape[2]
-    # bulk traffic per cell and step: each half step reads 9 values, writes 3
-    return grid, cells, 24 * es, dt, desc
+    return grid, cells, es, dt, desc
+
+
+def half_step_bytes(grid, cells, es, mask):
+    """Bytes one E and one H half step of one GPU have to move: the advanced field read
+    and written, the driving field read, the material array read unless the library
+    holds it as a constant (mask bit 1: inverse permittivity, 2: inverse permeability),
+    and the two live memory variables of every PML cell read and written."""
+    psi = sum(int(b._psiE.numel()) for b in grid.boundaries if getattr(b, "_psiE", None) is not None)
+    e = cells * (9 if mask & 1 else 12) * es + 2 * psi * es
+    h = cells * (9 if mask & 2 else 12) * es + 2 * psi * es
+    return e, h
+
+
+def timed_run(grid, lib, _lib, steps, sync):
+    """Time `steps` steps; returns (seconds, ms in E kernels, launches, ms in H kernels, launches)."""
+    plan = grid._plan
+    _lib.check(lib.fdtdhip_plan_enable_timing(plan, 1))
+    sync()
+    t0 = time.perf_counter()
+    grid.run(steps, progress_bar=False)
+    sync()
+    elapsed = time.perf_counter() - t0
+    msE, nE, msH, nH = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
+    _lib.check(lib.fdtdhip_plan_get_timing(plan, ctypes.byref(msE), ctypes.byref(nE),
+                                            ctypes.byref(msH), ctypes.byref(nH)))
+    _lib.check(lib.fdtdhip_plan_enable_timing(plan, 0))
+    return elapsed, msE.value, nE.value, msH.value, nH.value
+
+
+def use_material_arrays(grid, lib, _lib):
+    """Make the kernels read the material arrays whatever they hold."""
+    grid._ensure_plan()
+    grid._material_scans = grid._MAX_MATERIAL_SCANS + 1
+    _lib.check(lib.fdtdhip_plan_scan_materials(grid._plan, 0))
 
 
 def cpu_baseline(name, budget_s=15.0):
@@ -148,6 +188,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="m3v")
+    ap.add_argument("--materials", choices=("auto", "arrays"), default="auto")
+    ap.add_argument("--also-arrays", action="store_true",
+                    help="add an array_materials object: the same run with both material arrays read")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -173,7 +216,7 @@ def main():
     import fdtd_amd as fdtd
     from fdtd_amd import _lib
 
-    grid, cells, bytes_per_cell, dt, desc = build_workload(fdtd, args.workload, world, rank)
+    grid, cells, es, dt, desc = build_workload(fdtd, args.workload, world, rank)
     lib = _lib.load()
 
     def sync():
@@ -181,42 +224,52 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def roofline(ms_e, ms_h, mask, steps):
+        # dominant kernel: the bulk half-step kernel.  One half step of one GPU = `cells`
+        # cells = one bulk launch on a single GPU; on a slab it is two launches (interior
+        # planes, then the plane that waits for the halo), so durations are summed per
+        # half step before dividing.
+        be, bh = half_step_bytes(grid, cells, es, mask)
+        avg_ms = (ms_e + ms_h) / (2 * steps)
+        per_launch = (be + bh) / 2
+        achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        return {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "kernel": "bulk half-step kernel (E and H)",
+            "materials": {0: "arrays", 1: "inverse permittivity constant", 2: "inverse permeability constant",
+                          3: "constants"}[mask],
+            "bytes_per_launch": per_launch,
+            "avg_launch_ms": round(avg_ms, 4),
+            "avg_launch_ms_E": round(ms_e / steps, 4),
+            "avg_launch_ms_H": round(ms_h / steps, 4),
+        }
+
+    if args.materials == "arrays":
+        use_material_arrays(grid, lib, _lib)
     grid.run(args.warmup, progress_bar=False)
     sync()
-    plan = grid._plan
-    _lib.check(lib.fdtdhip_plan_enable_timing(plan, 1))
-    sync()
-    t0 = time.perf_counter()
-    grid.run(args.steps, progress_bar=False)
-    sync()
-    elapsed = time.perf_counter() - t0
-    msE, nE, msH, nH = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
-    _lib.check(lib.fdtdhip_plan_get_timing(plan, ctypes.byref(msE), ctypes.byref(nE),
-                                            ctypes.byref(msH), ctypes.byref(nH)))
-    _lib.check(lib.fdtdhip_plan_enable_timing(plan, 0))
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    mask = 0 if args.materials == "arrays" else _lib.check(lib.fdtdhip_plan_scan_materials(grid._plan, 1))
+    elapsed, msE, nE, msH, nH = timed_run(grid, lib, _lib, args.steps, sync)
+    elapsed = max_over_ranks(elapsed)
 
+    out = None
     if rank == 0:
-        total_cells = cells * world
-        value = total_cells * args.steps / elapsed / 1e9
-        # dominant kernel: the bulk half-step kernel (E and H variants move the same bytes)
-        # One half step of one GPU = `cells` cells = one bulk launch on a single GPU; on a
-        # slab it is two launches (interior planes, then the plane that waits for the
-        # halo), so durations are summed per half step before dividing.
-        launches = nE.value + nH.value
-        half_steps = 2 * args.steps
-        avg_ms = (msE.value + msH.value) / half_steps
-        bytes_per_launch = cells * bytes_per_cell / 2
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        value = cells * world * args.steps / elapsed / 1e9
+        roof = roofline(msE, msH, mask, args.steps)
+        roof["launches"] = nE + nH
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
-            rec = json.load(open(pmc)).get(args.workload)
+            rec = json.load(open(pmc)).get(f"{args.workload}:{roof['materials']}")
             if rec:
-                traffic = rec.get("bytes_per_launch")
+                roof["traffic"] = rec.get("bytes_per_launch")
         out = {
             "metric": "Yee cell-updates/s", "value": round(value, 3), "unit": "Gcells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -225,17 +278,21 @@ def main():
             "config": {"workload": desc, "name": args.workload,
                        "parallelism": f"x-slab x{world}" if world > 1 else "single GPU",
                        "cells_per_gpu": cells},
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "kernel": "bulk half-step kernel (E and H)",
-                "bytes_per_launch": bytes_per_launch,
-                "avg_launch_ms": round(avg_ms, 4),
-                "avg_launch_ms_E": round(msE.value / args.steps, 4),
-                "avg_launch_ms_H": round(msH.value / args.steps, 4),
-                "launches": launches,
-            },
+            "roofline": roof,
         }
+    if mask and world == 1 and args.also_arrays:
+        # the same grid with every kernel reading both material arrays
+        use_material_arrays(grid, lib, _lib)
+        grid.run(args.warmup, progress_bar=False)
+        sync()
+        el2, e2, _, h2, _ = timed_run(grid, lib, _lib, args.steps, sync)
+        r2 = roofline(e2, h2, 0, args.steps)
+        out["array_materials"] = {
+            "value": round(cells * args.steps / el2 / 1e9, 3), "unit": "Gcells/s",
+            "ms_per_step": round(el2 / args.steps * 1e3, 4),
+            "achieved": r2["achieved"], "frac": r2["frac"], "bytes_per_launch": r2["bytes_per_launch"],
+        }
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

@@ -29,6 +29,7 @@ PROTOTYPES = {
     "fdtdhip_plan_reset": (_i, [_p]),
     "fdtdhip_plan_set_stream": (_i, [_p, _p]),
     "fdtdhip_plan_set_fields": (_i, [_p, _p, _p, _p, _p]),
+    "fdtdhip_plan_scan_materials": (_i, [_p, _i]),
     "fdtdhip_plan_set_halo": (_i, [_p, _p, _p]),
     "fdtdhip_plan_set_step_buffers": (_i, [_p, _p, _p]),
     "fdtdhip_plan_set_pml_step_buffer": (_i, [_p, _i, _p]),

@@ -124,6 +124,11 @@ struct fdtdhip_plan {
   // device tables of PML descriptors, one per use (see PmlTab); rebuilt when dirty
   void* pml_tables = nullptr;
   bool pml_dirty = true;
+  // Outcome of fdtdhip_plan_scan_materials for inv_eps [0] and inv_mu [1]: the array is
+  // mat_bg outside the object boxes (zero inside, inv_eps only) and need not be read.
+  bool mat_const[2] = {false, false};
+  double mat_bg[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  int* scan_flag = nullptr;   // device word the scan kernel raises
   int64_t trace_cursor = -1;  // row of the curl traces the next E half step writes; -1: no traces
   std::vector<void*> owned;   // device allocations released by reset/destroy
   // optional kernel timing (fdtdhip_plan_enable_timing)
@@ -157,6 +162,7 @@ int release_tables(fdtdhip_plan* p) {
   p->sources.clear();
   p->dets.clear();
   p->obj_dirty = false;
+  p->mat_const[0] = p->mat_const[1] = false;
   return 0;
 }
 
@@ -340,6 +346,77 @@ int bulk(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
   return rc;
 }
 
+// The box of cells that no PML slab covers (slabs sit at the low or high end of their
+// axis) and the box that contains all objects.
+template <typename T>
+void fill_core(const fdtdhip_plan* p, BulkArgs<T>& a) {
+  int c[6] = {0, p->nx, 0, p->ny, 0, p->nz};
+  for (const PmlH& h : p->pmls) {
+    if (h.lo == 0) c[2 * h.axis] = std::max(c[2 * h.axis], h.t);
+    else c[2 * h.axis + 1] = std::min(c[2 * h.axis + 1], h.lo);
+  }
+  for (int n = 0; n < 6; ++n) a.core[n] = c[n];
+  int h[6] = {p->nx, 0, p->ny, 0, p->nz, 0};
+  for (const ObjH& o : p->objs)
+    for (int ax = 0; ax < 3; ++ax) {
+      h[2 * ax] = std::min(h[2 * ax], o.box[2 * ax]);
+      h[2 * ax + 1] = std::max(h[2 * ax + 1], o.box[2 * ax + 1]);
+    }
+  for (int n = 0; n < 6; ++n) a.hull[n] = h[n];
+  static const int rot = [] {
+    const char* e = getenv("FDTDHIP_ROT");
+    return e ? atoi(e) : 2;
+  }();
+  a.rot_shift = rot;
+}
+
+template <typename T>
+void fill_material(const fdtdhip_plan* p, bool phaseE, BulkArgs<T>& a) {
+  const int w = phaseE ? 0 : 1;
+  a.mat_const = p->mat_const[w] ? 1 : 0;
+  for (int c = 0; c < 3; ++c) a.bg[c] = (T)p->mat_bg[w][c];
+}
+
+// Decide whether one material array can be replaced by a constant (see cell_material).
+template <typename T>
+int scan_material(fdtdhip_plan* p, int w) {
+  p->mat_const[w] = false;
+  const T* mat = (const T*)(w == 0 ? p->inv_eps : p->inv_mu);
+  if (!mat) return 0;
+  if (int rc = sync_obj_table<T>(p)) return rc;
+  const int nobj = w == 0 ? (int)p->objs.size() : 0;
+  // a cell outside every object box gives the background value
+  const int64_t ncell = p->cells(), plane = (int64_t)p->ny * p->nz;
+  int64_t probe = -1;
+  for (int64_t cell = 0; cell < ncell && cell < 65536 && probe < 0; ++cell) {
+    const int i = (int)(cell / plane), j = (int)((cell / p->nz) % p->ny), k = (int)(cell % p->nz);
+    bool covered = false;
+    for (int o = 0; o < nobj; ++o) {
+      const int* b = p->objs[o].box;
+      covered |= i >= b[0] && i < b[1] && j >= b[2] && j < b[3] && k >= b[4] && k < b[5];
+    }
+    if (!covered) probe = cell;
+  }
+  if (probe < 0) return 0;
+  if (!p->scan_flag) HIPCHK(hipMalloc((void**)&p->scan_flag, sizeof(int)));
+  T bg[3];
+  int differs = 0;
+  HIPCHK(hipMemcpyAsync(bg, mat + probe * 3, sizeof(bg), hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipMemsetAsync(p->scan_flag, 0, sizeof(int), p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  hipLaunchKernelGGL((material_scan<T>), dim3(blocks_for(ncell)), dim3(256), 0, p->stream, mat,
+                     ncell, p->ny, p->nz, (const ObjK<T>*)p->obj_table, nobj, bg[0], bg[1], bg[2],
+                     p->scan_flag);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(&differs, p->scan_flag, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (!differs) {
+    p->mat_const[w] = true;
+    for (int c = 0; c < 3; ++c) p->mat_bg[w][c] = (double)bg[c];
+  }
+  return 0;
+}
+
 template <typename T>
 int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
   if (!p->E || !p->H || !p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
@@ -360,25 +437,35 @@ int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
   a.trace_step = phaseE ? p->trace_cursor : -1;
   if (int rc = sync_pml_tables<T>(p)) return rc;
   a.pml = pml_table<T>(p, phaseE ? TAB_E : TAB_H);
+  fill_core<T>(p, a);
+  fill_material<T>(p, phaseE, a);
 
   const bool pml = a.npml > 0, obj = a.nobj > 0;
   const int64_t plane = (int64_t)p->ny * p->nz;
   const Strategy st = strategy();
   const dim3 block(256);
 
-  // Measured on MI355X (512^3 and 256^3, tools/kbench): float32 runs fastest with the
-  // unconditional-load kernel, flat lane mapping and non-temporal access to the
-  // streamed arrays (5.8 TB/s algorithmic, the rate of a plain 3-read-1-write
-  // stream); float64 cells are 24 B, every load splits in a 16 B and an 8 B
-  // instruction that touch the same lines, non-temporal lines are dropped between
-  // the two, and the one-lane-per-cell kernel with plain loads is fastest.
-  const bool fast = st.chosen ? st.fast : sizeof(T) == 4;
-  if (fast && (st.force || plane >= 4096) && (x1 - x0) <= 65535 && plane < (1ll << 30)) {
+  // Measured on MI355X (512^3 and 256^3, tools/kbench, run-to-run spread about 3 %).
+  // float32: a wave per z-row segment with rotated segments (see lane_cell),
+  // non-temporal loads of the streamed arrays and non-temporal stores: 6.0 TB/s
+  // algorithmic with material arrays, 5.8 TB/s of the smaller traffic with constant
+  // materials (a plain 3-read-1-write float4 stream reaches 5.85 TB/s here).
+  // float64: cells are 24 B, every load splits in a 16 B and an 8 B instruction that
+  // touch the same lines and non-temporal lines are dropped between the two, so plain
+  // loads and non-temporal stores; lane mapping makes no measurable difference, flat
+  // is used (5.0-5.2 TB/s).
+  Strategy use = st;
+  if (!st.chosen) {
+    use.fast = true;
+    use.ntl = sizeof(T) == 4;
+    use.nts = true;
+    use.flat = sizeof(T) == 8;
+  }
+  if (use.fast && (st.force || plane >= 4096) && (x1 - x0) <= 65535 && plane < (1ll << 30)) {
     // flat: 256 consecutive cells per workgroup; rows: a wave per z-row segment
-    const bool flat = st.flat || p->nz < 48;
+    const bool flat = use.flat || p->nz < 48 || (p->ny + 3) / 4 > 65535;
     const dim3 grid = flat ? dim3((unsigned)((plane + 255) / 256), x1 - x0, 1)
                            : dim3((p->nz + 63) / 64, (p->ny + 3) / 4, x1 - x0);
-    if (!flat && grid.y > 65535) return fail(-1, "grid too tall for the row kernel");
 #define FAST(FLAT, NT, NTS)                                                                         \
   if (phaseE) {                                                                                     \
     if (pml && obj) hipLaunchKernelGGL((bulk_E_rows<T, true, true, FLAT, NT, NTS>), grid, block, 0, p->stream, a);   \
@@ -390,9 +477,9 @@ int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
     else hipLaunchKernelGGL((bulk_H_rows<T, false, FLAT, NT, NTS>), grid, block, 0, p->stream, a);     \
   }
 #define FAST2(FLAT)                                                     \
-  if (st.ntl && st.nts) { FAST(FLAT, true, true) }                      \
-  else if (st.ntl) { FAST(FLAT, true, false) }                          \
-  else if (st.nts) { FAST(FLAT, false, true) }                          \
+  if (use.ntl && use.nts) { FAST(FLAT, true, true) }                    \
+  else if (use.ntl) { FAST(FLAT, true, false) }                         \
+  else if (use.nts) { FAST(FLAT, false, true) }                         \
   else { FAST(FLAT, false, false) }
     if (flat) { FAST2(true) } else { FAST2(false) }
 #undef FAST2
@@ -660,6 +747,8 @@ int fused_step(fdtdhip_plan* p, int64_t q) {
     b.nobj = phaseE ? (int)p->objs.size() : 0;
     b.obj = (const ObjK<T>*)p->obj_table;
     b.trace_step = -1;
+    b.mat_const = 0;  // the fused step reads the arrays
+    fill_core<T>(p, b);
   }
   if (int rc = sync_pml_tables<T>(p)) return rc;
   // p->step_flipped: the state currently lives in the second buffers
@@ -679,16 +768,6 @@ int fused_step(fdtdhip_plan* p, int64_t q) {
   const int64_t plane = (int64_t)p->ny * p->nz;
   const dim3 grid((unsigned)((plane + 255) / 256), p->nx, 1), block(256);
   const bool pml = a.e.npml > 0, obj = a.e.nobj > 0;
-  // one-lane-per-cell form unless FDTDHIP_STEP=march asks for the marching form
-  static const int step_form = [] {
-    const char* e = getenv("FDTDHIP_STEP");
-    return e ? (std::string(e) == "simple" ? 1 : 2) : 0;
-  }();
-  static const int xchunk_env = [] {
-    const char* e = getenv("FDTDHIP_XCHUNK");
-    return e ? atoi(e) : 0;
-  }();
-  const bool march = step_form == 2;
   size_t slot = 0;
   if (p->timing) {
     if (p->ev_phase.size() >= 2048)
@@ -702,16 +781,7 @@ int fused_step(fdtdhip_plan* p, int64_t q) {
     }
     HIPCHK(hipEventRecord(p->ev_pool[slot].first, p->stream));
   }
-  if (march) {
-    constexpr int NW = 8;
-    const int xchunk = xchunk_env > 0 ? xchunk_env : 32;
-    const dim3 mgrid((p->nz + 62) / 63, (p->ny + NW - 2) / (NW - 1), (p->nx + xchunk - 1) / xchunk);
-    const dim3 mblock(NW * 64);
-    if (pml && obj) hipLaunchKernelGGL((step_march<T, NW, true, true>), mgrid, mblock, 0, p->stream, a, xchunk);
-    else if (pml) hipLaunchKernelGGL((step_march<T, NW, true, false>), mgrid, mblock, 0, p->stream, a, xchunk);
-    else if (obj) hipLaunchKernelGGL((step_march<T, NW, false, true>), mgrid, mblock, 0, p->stream, a, xchunk);
-    else hipLaunchKernelGGL((step_march<T, NW, false, false>), mgrid, mblock, 0, p->stream, a, xchunk);
-  } else if (pml && obj) hipLaunchKernelGGL((step_fused<T, true, true>), grid, block, 0, p->stream, a);
+  if (pml && obj) hipLaunchKernelGGL((step_fused<T, true, true>), grid, block, 0, p->stream, a);
   else if (pml) hipLaunchKernelGGL((step_fused<T, true, false>), grid, block, 0, p->stream, a);
   else if (obj) hipLaunchKernelGGL((step_fused<T, false, true>), grid, block, 0, p->stream, a);
   else hipLaunchKernelGGL((step_fused<T, false, false>), grid, block, 0, p->stream, a);
@@ -773,6 +843,7 @@ int fdtdhip_plan_destroy(fdtdhip_plan* p) {
     (void)hipStreamSynchronize(p->stream);
     release_tables(p);
     if (p->pml_tables) (void)hipFree(p->pml_tables);
+    if (p->scan_flag) (void)hipFree(p->scan_flag);
     for (auto& e : p->ev_pool) {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
@@ -792,8 +863,25 @@ int fdtdhip_plan_set_fields(fdtdhip_plan* p, void* E, void* H, const void* inv_e
                             const void* inv_mu) {
   if (!p) return fail(-1, "null plan");
   if (!E || !H || !inv_eps || !inv_mu) return fail(-1, "null field pointer");
+  // a new material array has not been scanned
+  if (inv_eps != p->inv_eps) p->mat_const[0] = false;
+  if (inv_mu != p->inv_mu) p->mat_const[1] = false;
   p->E = E; p->H = H; p->inv_eps = inv_eps; p->inv_mu = inv_mu;
   return 0;
+}
+
+int fdtdhip_plan_scan_materials(fdtdhip_plan* p, int enable) {
+  if (!p) return fail(-1, "null plan");
+  static const bool off = [] {
+    const char* e = getenv("FDTDHIP_MATERIAL_SCAN");
+    return e && atoi(e) == 0;
+  }();
+  p->mat_const[0] = p->mat_const[1] = false;
+  if (off || !enable) return 0;
+  DeviceGuard g(p->device);
+  for (int w = 0; w < 2; ++w)
+    if (int rc = DISPATCH(p, scan_material<float>(p, w), scan_material<double>(p, w))) return rc;
+  return (p->mat_const[0] ? 1 : 0) | (p->mat_const[1] ? 2 : 0);
 }
 
 int fdtdhip_plan_set_step_buffers(fdtdhip_plan* p, void* E_alt, void* H_alt) {
@@ -874,6 +962,7 @@ int fdtdhip_plan_add_object(fdtdhip_plan* p, int kind, const int32_t box[6], con
   h.absorb = absorb;
   p->objs.push_back(h);
   p->obj_dirty = true;
+  p->mat_const[0] = false;  // the box was zeroed after any earlier scan
   return (int)p->objs.size() - 1;
 }
 

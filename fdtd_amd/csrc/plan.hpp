@@ -58,6 +58,15 @@ struct BulkArgs {
   const ObjK<T>* obj;
   int64_t trace_step;  // row of the objects' curl traces to write (forward) / read (adjoint); -1: none
   const PmlK<T>* pml;  // device table of npml descriptors (read with scalar loads, one at a time)
+  int mat_const;       // 1: `mat` was scanned and holds `bg` in every cell outside the object
+                       // boxes and zero inside them; the kernels then do not read it
+  T bg[3];
+  int rot_shift;       // row kernel: the z segment of a workgroup advances by one every
+                       // 2^rot_shift block rows (see lane_cell)
+  int hull[6];         // x0,x1,y0,y1,z0,z1 of the box that contains every object: a wavefront
+                       // with no cell inside it skips the object table
+  int core[6];         // x0,x1,y0,y1,z0,z1 of the box no PML slab reaches: a wavefront whose
+                       // cells all lie inside it skips the PML table altogether
 };
 
 // Arguments of the adjoint (reverse-time) half-step kernels.  For the adjoint of

@@ -72,6 +72,9 @@ struct Diffs {
 template <typename T, bool PHASE_E>
 __device__ __forceinline__ void pml_all(const BulkArgs<T>& a, int i, int j, int k,
                                         const Diffs<T>& d, T f[3], const T m[3], bool store) {
+  const bool in_core = i >= a.core[0] && i < a.core[1] && j >= a.core[2] && j < a.core[3] &&
+                       k >= a.core[4] && k < a.core[5];
+  if (__all(in_core)) return;
   for (int p = 0; p < a.npml; ++p) {
     const PmlK<T> P = a.pml[p];
     if (P.axis == 0) pml_face<T, 0>(P, a.nx, i, j, k, d.x_y, d.x_z, PHASE_E, a.sc, f, m, store);
@@ -85,6 +88,12 @@ __device__ __forceinline__ void pml_all(const BulkArgs<T>& a, int i, int j, int 
 // and correction.  `e` holds the cell's E on entry and the new E on return.
 // store = false evaluates the cell without side effects (no memory-variable or trace
 // writes): used when a lane re-derives a neighbour's new E in the fused full step.
+template <typename T>
+__device__ __forceinline__ bool in_hull(const BulkArgs<T>& a, int i, int j, int k) {
+  return i >= a.hull[0] && i < a.hull[1] && j >= a.hull[2] && j < a.hull[3] && k >= a.hull[4] &&
+         k < a.hull[5];
+}
+
 template <typename T, bool HAS_PML, bool HAS_OBJ>
 __device__ __forceinline__ void finish_E(const BulkArgs<T>& a, int i, int j, int k,
                                          const Diffs<T>& d, T e[3], const T m[3],
@@ -96,7 +105,7 @@ __device__ __forceinline__ void finish_E(const BulkArgs<T>& a, int i, int j, int
 #pragma unroll
   for (int c = 0; c < 3; ++c) e[c] += (a.sc * m[c]) * cu[c];
 
-  if (HAS_OBJ) {
+  if (HAS_OBJ && __any(in_hull(a, i, j, k))) {
     for (int o = 0; o < a.nobj; ++o) {
       const ObjK<T> O = a.obj[o];
       if (i < O.x0 || i >= O.x1 || j < O.y0 || j >= O.y1 || k < O.z0 || k >= O.z1) continue;
@@ -149,6 +158,63 @@ __device__ __forceinline__ void finish_H(const BulkArgs<T>& a, int i, int j, int
   if (HAS_PML) pml_all<T, false>(a, i, j, k, d, h, m, store);
 }
 
+// Inverse material of one cell.  Grids are usually homogeneous outside their objects
+// (reference fdtd/grid.py:135-151 fills both arrays with one value; fdtd/objects.py:90
+// zeroes the inverse permittivity under an object), and a scan of the array
+// (material_scan below) can prove it: the value is then a kernel argument and a
+// quarter of the half step's memory traffic disappears.  The result is the same
+// either way -- the constant is the value the array holds.
+template <typename T, bool NT, bool HAS_OBJ>
+__device__ __forceinline__ void cell_material(const BulkArgs<T>& a, int64_t c3, int i, int j,
+                                              int k, T m[3]) {
+  if (a.mat_const) {
+    bool covered = false;
+    if (HAS_OBJ && __any(in_hull(a, i, j, k)))
+      for (int o = 0; o < a.nobj; ++o) {
+        const ObjK<T> O = a.obj[o];
+        covered |= i >= O.x0 && i < O.x1 && j >= O.y0 && j < O.y1 && k >= O.z0 && k < O.z1;
+      }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) m[c] = covered ? T(0) : a.bg[c];
+  } else if (NT) {
+    m[0] = __builtin_nontemporal_load(a.mat + c3);
+    m[1] = __builtin_nontemporal_load(a.mat + c3 + 1);
+    m[2] = __builtin_nontemporal_load(a.mat + c3 + 2);
+  } else {
+    m[0] = a.mat[c3]; m[1] = a.mat[c3 + 1]; m[2] = a.mat[c3 + 2];
+  }
+}
+
+__device__ __forceinline__ bool same_bits(float x, float y) {
+  return __float_as_uint(x) == __float_as_uint(y);
+}
+__device__ __forceinline__ bool same_bits(double x, double y) {
+  return __double_as_longlong(x) == __double_as_longlong(y);
+}
+
+// Sets *differs when some cell of `mat` is not, bit for bit, bg outside the nobj
+// boxes and +0 inside them.
+template <typename T>
+__global__ __launch_bounds__(256) void material_scan(const T* __restrict__ mat, int64_t ncell,
+                                                     int ny, int nz, const ObjK<T>* obj,
+                                                     int nobj, T bg0, T bg1, T bg2,
+                                                     int* differs) {
+  const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= ncell) return;
+  bool covered = false;
+  if (nobj) {
+    const int k = (int)(cell % nz), j = (int)((cell / nz) % ny), i = (int)(cell / ((int64_t)nz * ny));
+    for (int o = 0; o < nobj; ++o) {
+      const ObjK<T> O = obj[o];
+      covered |= i >= O.x0 && i < O.x1 && j >= O.y0 && j < O.y1 && k >= O.z0 && k < O.z1;
+    }
+  }
+  const T* m = mat + cell * 3;
+  const bool ok = same_bits(m[0], covered ? T(0) : bg0) && same_bits(m[1], covered ? T(0) : bg1) &&
+                  same_bits(m[2], covered ? T(0) : bg2);
+  if (!ok) *differs = 1;
+}
+
 // Block index -> block of work.  With BAND, the 8 XCDs (blocks are dealt to them
 // round robin, so blocks b and b+8 share an L2) each take a contiguous band of
 // rows of every x plane: the y- and x-neighbours of a cell are then fetched by
@@ -185,7 +251,8 @@ __global__ __launch_bounds__(256) void bulk_E_generic(BulkArgs<T> a) {
   else if (a.ghost) { d.x_z = hz - a.ghost[r * 3 + 2]; d.x_y = hy - a.ghost[r * 3 + 1]; }
 
   T e[3] = {a.F[c3], a.F[c3 + 1], a.F[c3 + 2]};
-  const T m[3] = {a.mat[c3], a.mat[c3 + 1], a.mat[c3 + 2]};
+  T m[3];
+  cell_material<T, false, HAS_OBJ>(a, c3, i, j, k, m);
   finish_E<T, HAS_PML, HAS_OBJ>(a, i, j, k, d, e, m);
   a.F[c3] = e[0];
   a.F[c3 + 1] = e[1];
@@ -220,7 +287,8 @@ __global__ __launch_bounds__(256) void bulk_H_generic(BulkArgs<T> a) {
   else if (a.ghost) { d.x_z = a.ghost[r * 3 + 2] - ez; d.x_y = a.ghost[r * 3 + 1] - ey; }
 
   T h[3] = {a.F[c3], a.F[c3 + 1], a.F[c3 + 2]};
-  const T m[3] = {a.mat[c3], a.mat[c3 + 1], a.mat[c3 + 2]};
+  T m[3];
+  cell_material<T, false, false>(a, c3, i, j, k, m);
   finish_H<T, HAS_PML>(a, i, j, k, d, h, m);
   a.F[c3] = h[0];
   a.F[c3 + 1] = h[1];

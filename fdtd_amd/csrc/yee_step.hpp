@@ -15,7 +15,12 @@
 // neighbour values are bit-identical to what their owner lanes store (same
 // operations, same operands), so the result equals two separate half steps.
 // The extra loads of the neighbourhood (13 cells of H0, 4 of E0 and eps) are
-// L1/L2 hits; HBM sees each array once.
+// L1/L2 hits; HBM sees each array once.  Those 26 loads per lane make the kernel
+// L1-bound on large grids (512^3 fp32: 3.2 ms a step against 2.2 ms for two half
+// steps), so the plan uses it where launch count decides the step time: small
+// grids.  A marching variant that carried planes in registers and exchanged
+// neighbours through LDS cut the loads to 8 per cell but its strided 756-byte row
+// segments cost more DRAM efficiency than the saved traffic returned (2.33 ms).
 //
 // Side effects stay with the owner lane: only it stores the PML memory variables
 // (psi_E to the second psi buffer, because neighbours still read the old one) and
@@ -80,7 +85,7 @@ __device__ __forceinline__ void new_E(const StepArgs<T>& a, int i, int j, int k,
 template <typename T, bool HAS_PML, bool HAS_OBJ>
 __global__ __launch_bounds__(256) void step_fused(StepArgs<T> a) {
   int i, j, k;
-  if (!lane_cell<true>(0, a.e.ny, a.e.nz, i, j, k)) return;
+  if (!lane_cell<true>(0, a.e.ny, a.e.nz, 0, i, j, k)) return;
   const int nx = a.e.nx, ny = a.e.ny, nz = a.e.nz;
   const int64_t sz = 3, sy = 3 * (int64_t)nz, sx = sy * ny;
   const int64_t c3 = (int64_t)i * sx + (int64_t)j * sy + 3 * k;
@@ -127,105 +132,6 @@ __global__ __launch_bounds__(256) void step_fused(StepArgs<T> a) {
   load3<T, true>(a.h.mat + c3, m[0], m[1], m[2]);
   finish_H<T, HAS_PML>(a.h, i, j, k, d, hc, m);
   store3<T, true>(a.H1 + c3, hc[0], hc[1], hc[2]);
-}
-
-// ---------------------------------------------------------------------------
-// Fused full step, marching form (large grids).
-//
-// The one-lane-per-cell form above re-derives three neighbour values per cell from
-// 13 + 4 + 4 neighbourhood loads; that is too much L1/TA traffic to win on a big
-// grid.  Here a workgroup of NW wavefronts owns (NW-1) rows x 63 cells of z and
-// walks along x over a chunk of planes:
-//   * the new E of the forward x neighbour is simply the next iteration's value
-//     (the H update of plane p-1 is done in iteration p), and H0 of the backward
-//     x neighbour is the previous iteration's load, both carried in registers;
-//   * the new E of the forward y neighbour comes from the wavefront of the next
-//     row through LDS, that of the forward z neighbour from the next lane by a
-//     wavefront shuffle;
-//   * wavefront NW-1 and lane 63 are halo: they derive the new E of the row / cell
-//     just beyond the tile (owned by the neighbouring tile) and store nothing.
-// Per owned cell and step: 6 global loads of 3 components (H0, H0 row below, H0
-// cell before, E0, eps, mu) instead of 14 in two separate half steps.
-template <typename T, int NW, bool HAS_PML, bool HAS_OBJ>
-__global__ __launch_bounds__(NW * 64) void step_march(StepArgs<T> a, int xchunk) {
-  __shared__ T xch[2][NW][64][3];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nx = a.e.nx, ny = a.e.ny, nz = a.e.nz;
-  const int k_raw = blockIdx.x * 63 + lane, j_raw = blockIdx.y * (NW - 1) + w;
-  const bool in = k_raw < nz && j_raw < ny;
-  const bool owner = in && lane < 63 && w < NW - 1;
-  const int k = k_raw < nz ? k_raw : nz - 1, j = j_raw < ny ? j_raw : ny - 1;  // safe addresses
-  const int xa = blockIdx.z * xchunk;
-  const int xb = xa + xchunk < nx ? xa + xchunk : nx;
-  const int64_t sy = 3 * (int64_t)nz, sx = sy * ny;
-  const int64_t r3 = (int64_t)j * sy + 3 * k;
-  const int64_t ym = j > 0 ? -sy : 0, zm = k > 0 ? -3 : 0;
-  const bool hasyp = j < ny - 1, haszp = k < nz - 1;
-
-  T hprev[3] = {0, 0, 0};                 // H0 of the plane before, at this cell
-  T eprev[3] = {0, 0, 0};                 // new E of the plane before: this cell,
-  T eprev_yp[3] = {0, 0, 0};              // its forward y neighbour,
-  T eprev_zp[3] = {0, 0, 0};              // its forward z neighbour
-  if (xa > 0) load3<T, false>(a.e.G + (int64_t)(xa - 1) * sx + r3, hprev[0], hprev[1], hprev[2]);
-
-  for (int p = xa; p <= xb; ++p) {
-    const int64_t c3 = (int64_t)(p < nx ? p : nx - 1) * sx + r3;
-    T e1[3] = {0, 0, 0}, hc[3] = {0, 0, 0};
-    if (p < nx) {
-      const T* H0 = a.e.G + c3;
-      T hym[3], hzm[3];
-      load3<T, false>(H0, hc[0], hc[1], hc[2]);
-      load3<T, false>(H0 + ym, hym[0], hym[1], hym[2]);
-      load3<T, false>(H0 + zm, hzm[0], hzm[1], hzm[2]);
-      Diffs<T> d;
-      const bool hasx = p > 0, hasy = j > 0, hasz = k > 0;
-      d.x_y = hasx ? hc[1] - hprev[1] : T(0);
-      d.x_z = hasx ? hc[2] - hprev[2] : T(0);
-      d.y_x = hasy ? hc[0] - hym[0] : T(0);
-      d.y_z = hasy ? hc[2] - hym[2] : T(0);
-      d.z_x = hasz ? hc[0] - hzm[0] : T(0);
-      d.z_y = hasz ? hc[1] - hzm[1] : T(0);
-      T m[3];
-      load3<T, true>(a.e.F + c3, e1[0], e1[1], e1[2]);
-      load3<T, true>(a.e.mat + c3, m[0], m[1], m[2]);
-      const bool mine = owner && p < xb;  // plane xb belongs to the next chunk
-      finish_E<T, HAS_PML, HAS_OBJ>(a.e, p, j, k, d, e1, m, mine);
-      add_sources<T>(a, c3, e1);
-      if (mine) store3<T, true>(a.E1 + c3, e1[0], e1[1], e1[2]);
-    }
-    // hand the new E to the row below (LDS) and the lane before (shuffle)
-    T(*slot)[64][3] = xch[p & 1];
-    slot[w][lane][0] = e1[0];
-    slot[w][lane][1] = e1[1];
-    slot[w][lane][2] = e1[2];
-    __syncthreads();
-    const int wn = w < NW - 1 ? w + 1 : w;
-    const T e1_yp[3] = {slot[wn][lane][0], slot[wn][lane][1], slot[wn][lane][2]};
-    const T e1_zp[3] = {__shfl_down(e1[0], 1), __shfl_down(e1[1], 1), __shfl_down(e1[2], 1)};
-
-    if (p > xa) {  // H half step of plane p-1
-      const int64_t q3 = (int64_t)(p - 1) * sx + r3;
-      Diffs<T> d;
-      const bool hasxp = p < nx;
-      d.x_y = hasxp ? e1[1] - eprev[1] : T(0);
-      d.x_z = hasxp ? e1[2] - eprev[2] : T(0);
-      d.y_x = hasyp ? eprev_yp[0] - eprev[0] : T(0);
-      d.y_z = hasyp ? eprev_yp[2] - eprev[2] : T(0);
-      d.z_x = haszp ? eprev_zp[0] - eprev[0] : T(0);
-      d.z_y = haszp ? eprev_zp[1] - eprev[1] : T(0);
-      T m[3];
-      load3<T, true>(a.h.mat + q3, m[0], m[1], m[2]);
-      finish_H<T, HAS_PML>(a.h, p - 1, j, k, d, hprev, m, owner);
-      if (owner) store3<T, true>(a.H1 + q3, hprev[0], hprev[1], hprev[2]);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      eprev[c] = e1[c];
-      eprev_yp[c] = e1_yp[c];
-      eprev_zp[c] = e1_zp[c];
-      hprev[c] = hc[c];
-    }
-  }
 }
 
 }  // namespace fdtdhip

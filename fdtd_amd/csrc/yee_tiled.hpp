@@ -45,7 +45,8 @@ __device__ __forceinline__ void store3(T* p, T x, T y, T z) {
 // workgroup (grid = blocks per plane x planes); otherwise a wave per z-row segment
 // (grid = z tiles x row quads x planes).
 template <bool FLAT>
-__device__ __forceinline__ bool lane_cell(int x0, int ny, int nz, int& i, int& j, int& k) {
+__device__ __forceinline__ bool lane_cell(int x0, int ny, int nz, int rot_shift, int& i, int& j,
+                                          int& k) {
   if (FLAT) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     i = x0 + blockIdx.y;
@@ -53,7 +54,13 @@ __device__ __forceinline__ bool lane_cell(int x0, int ny, int nz, int& i, int& j
     k = r - j * nz;
     return j < ny;
   }
-  k = blockIdx.x * 64 + (threadIdx.x & 63);
+  // Workgroups are dealt to the 8 XCDs round robin along blockIdx.x first.  When the
+  // number of z segments is a multiple of 8 an unrotated mapping would give each XCD one
+  // fixed z segment: good for reuse (x and y neighbours were fetched by the same XCD's
+  // L2) but every cell of the z-low and z-high PML faces would land on two XCDs.
+  // Rotating the segment by one every 16 block rows keeps nearly all of the reuse and
+  // spreads the faces.
+  k = ((blockIdx.x + (blockIdx.y >> rot_shift)) % gridDim.x) * 64 + (threadIdx.x & 63);
   j = blockIdx.y * 4 + (threadIdx.x >> 6);
   i = x0 + blockIdx.z;
   return k < nz && j < ny;
@@ -62,7 +69,7 @@ __device__ __forceinline__ bool lane_cell(int x0, int ny, int nz, int& i, int& j
 template <typename T, bool HAS_PML, bool HAS_OBJ, bool FLAT, bool NT, bool NTS>
 __global__ __launch_bounds__(256) void bulk_E_rows(BulkArgs<T> a) {
   int i, j, k;
-  if (!lane_cell<FLAT>(a.x0, a.ny, a.nz, i, j, k)) return;
+  if (!lane_cell<FLAT>(a.x0, a.ny, a.nz, a.rot_shift, i, j, k)) return;
   const int64_t sy = 3 * (int64_t)a.nz, sx = sy * a.ny;
   const int64_t r3 = (int64_t)j * sy + 3 * k;
   const int64_t c3 = (int64_t)i * sx + r3;
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(256) void bulk_E_rows(BulkArgs<T> a) {
   load3<T, false>(gz, zx, zy, zz_);
   T e[3], m[3];
   load3<T, NT>(a.F + c3, e[0], e[1], e[2]);
-  load3<T, NT>(a.mat + c3, m[0], m[1], m[2]);
+  cell_material<T, NT, HAS_OBJ>(a, c3, i, j, k, m);
   (void)xx; (void)yy; (void)zz_;
 
   Diffs<T> d;
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256) void bulk_E_rows(BulkArgs<T> a) {
 template <typename T, bool HAS_PML, bool FLAT, bool NT, bool NTS>
 __global__ __launch_bounds__(256) void bulk_H_rows(BulkArgs<T> a) {
   int i, j, k;
-  if (!lane_cell<FLAT>(a.x0, a.ny, a.nz, i, j, k)) return;
+  if (!lane_cell<FLAT>(a.x0, a.ny, a.nz, a.rot_shift, i, j, k)) return;
   const int64_t sy = 3 * (int64_t)a.nz, sx = sy * a.ny;
   const int64_t r3 = (int64_t)j * sy + 3 * k;
   const int64_t c3 = (int64_t)i * sx + r3;
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256) void bulk_H_rows(BulkArgs<T> a) {
   load3<T, false>(gz, zx, zy, zz_);
   T h[3], m[3];
   load3<T, NT>(a.F + c3, h[0], h[1], h[2]);
-  load3<T, NT>(a.mat + c3, m[0], m[1], m[2]);
+  cell_material<T, NT, false>(a, c3, i, j, k, m);
   (void)xx; (void)yy; (void)zz_;
 
   Diffs<T> d;

@@ -265,9 +265,11 @@ class Grid:
                 for thing in group:
                     thing._native_add(lib, self._plan)
             self._plan_signature = sig
+            self._materials_key = None
         _lib.check(lib.fdtdhip_plan_set_stream(self._plan, _stream_ptr(bd.device)))
         _lib.check(lib.fdtdhip_plan_set_fields(
             self._plan, E.data_ptr(), H.data_ptr(), ie.data_ptr(), im.data_ptr()))
+        self._scan_materials(lib, ie, im)
         alt = getattr(self, "_step_buffers", None)
         if alt is not None and (alt[0].shape != E.shape or alt[0].dtype != E.dtype
                                 or alt[0].device != E.device):
@@ -279,6 +281,32 @@ class Grid:
             self._plan, lo.data_ptr() if lo is not None else None,
             hi.data_ptr() if hi is not None else None))
         return lib
+
+    _MAX_MATERIAL_SCANS = 4
+
+    def _scan_materials(self, lib, ie, im):
+        """Let the library find out whether the material arrays are constant outside
+        the objects (it then stops reading them).  Every in-place write to a tensor
+        bumps its version counter, so a changed array is scanned again before the
+        next half step; arrays that keep changing are scanned a few times and then
+        simply read by the kernels.  Writes that bypass the counter (``tensor.data``,
+        foreign code holding the pointer) must be followed by ``materials_changed()``."""
+        key = (ie.data_ptr(), ie._version, im.data_ptr(), im._version)
+        last = getattr(self, "_materials_key", None)
+        if key == last:
+            return
+        self._materials_key = key
+        scans = getattr(self, "_material_scans", 0)
+        if last is not None:  # the arrays changed under an unchanged plan
+            self._material_scans = scans = scans + 1
+        _lib.check(lib.fdtdhip_plan_scan_materials(
+            self._plan, 1 if scans < self._MAX_MATERIAL_SCANS else 0))
+
+    def materials_changed(self):
+        """Tell the grid that inverse_permittivity / inverse_permeability were written
+        to in a way torch does not see; they are examined again before the next step."""
+        self._materials_key = None
+        self._material_scans = 0
 
     def __del__(self):
         plan, self._plan = getattr(self, "_plan", None), None

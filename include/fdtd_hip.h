@@ -192,6 +192,24 @@ int fdtdhip_plan_set_object_grad(fdtdhip_plan* plan, int id, void* grad);
 int fdtdhip_plan_set_pml_adjoint(fdtdhip_plan* plan, int id, void* lam_psiE, void* lam_psiH);
 int fdtdhip_adjoint_run(fdtdhip_plan* plan, int64_t nsteps, void* lamE, void* lamH, void* work);
 
+/* Optional: prove that the material arrays need not be read.  The reference fills
+ * inverse_permittivity and inverse_permeability with one value (fdtd/grid.py:135-151)
+ * and an object zeroes the inverse permittivity in its box (fdtd/objects.py:90), so
+ * most grids hold a constant outside their objects.  This call reads both arrays once
+ * on the plan's stream and waits for the answer; an array that is bit for bit
+ * "constant outside the registered object boxes, +0 inside" (inverse permeability:
+ * constant everywhere) is from then on passed to the half-step kernels as that
+ * constant -- same results, a quarter less memory traffic.  Returns a bit mask
+ * (1: inverse permittivity, 2: inverse permeability) or a negative error.
+ * The finding lasts until fdtdhip_plan_set_fields names another array,
+ * fdtdhip_plan_add_object or fdtdhip_plan_reset is called, or this function is
+ * called again.  A caller that writes into a scanned array MUST call this function
+ * again before the next half step; a caller that never calls it gets kernels that
+ * read the arrays in full.  enable = 0 only forgets earlier findings (for arrays
+ * that change every step).  FDTDHIP_MATERIAL_SCAN=0 in the environment turns the
+ * scan into a no-op returning 0. */
+int fdtdhip_plan_scan_materials(fdtdhip_plan* plan, int enable);
+
 /* Kernel timing for benchmarks (the reference only has wall-clock timing around
  * grid.run, examples/old/simulation_benchmark.py:96-107).  While enabled, every
  * bulk kernel launch is bracketed by HIP events on the plan's stream.

@@ -1,0 +1,160 @@
+"""The large-grid kernels (the ones bench.py measures) against the oracle and against
+each other, on a real MI355X.
+
+The library picks its kernels by plane size: grids whose (y, z) plane has 4096 cells
+or more run the unconditional-load kernels (flat or row lane mapping, non-temporal
+access), smaller ones the shape-agnostic kernels the golden scenes exercise.  Here
+the grids are large enough for the former and small enough for the numpy oracle to
+follow in seconds; at the benchmark's full size (512^3) the checks are
+size-independent properties: the constant-material and array-material paths agree
+bit for bit, and a source moved by whole cells moves its field with it.
+
+Tolerances: float64 relative L2 <= 1e-12, float32 <= 1e-5 (against the float64 oracle).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import fdtd_amd as fdtd
+from fdtd_amd import _lib
+from oracle import yee_numpy as orc
+from test_hip_parity import TOL, host, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(shape, rs, dense, periodic_y=False):
+    """The same scene in the engine and in the oracle.  dense: random material arrays
+    (the kernels must read them); otherwise homogeneous ones (read as constants)."""
+    g, o = fdtd.Grid(shape), orc.OracleGrid(shape)
+    nx, ny, nz = shape
+    E0, H0 = 1e-2 * rs.randn(*shape, 3), 1e-2 * rs.randn(*shape, 3)
+    o.E[...], o.H[...] = E0, H0
+    g.E, g.H = fdtd.backend.array(E0), fdtd.backend.array(H0)
+    if dense:
+        ie, im = 1.0 / (1 + rs.rand(*shape, 3)), 1.0 / (1 + 0.2 * rs.rand(*shape, 3))
+        o.inverse_permittivity[...], o.inverse_permeability[...] = ie, im
+        g.inverse_permittivity = fdtd.backend.array(ie)
+        g.inverse_permeability = fdtd.backend.array(im)
+    faces = [(0, "low", 5), (0, "high", 4), (2, "low", 6), (2, "high", 5)]
+    if not periodic_y:
+        faces += [(1, "low", 4), (1, "high", 6)]
+    for axis, side, t in faces:
+        key = [slice(None)] * 3
+        key[axis] = slice(0, t) if side == "low" else slice(-t, None)
+        g[tuple(key)] = fdtd.PML()
+        o.add_pml(axis, side, t)
+    if periodic_y:
+        g[:, 0, :] = fdtd.PeriodicBoundary()
+        o.add_periodic(1)
+    box = (7, 15, 9, 30, 8, 25)
+    g[7:15, 9:30, 8:25] = fdtd.AnisotropicObject(permittivity=2.5)
+    oa = o.add_object(box, 2.5, kind="anisotropic")
+    off = 0.02 * rs.randn(8, 21, 17, 3, 3)
+    oa.inverse_permittivity += off
+    with torch.no_grad():
+        g.objects[0].inverse_permittivity += fdtd.backend.array(off)
+    g[12:20, 25:40, 20:28] = fdtd.AbsorbingObject(permittivity=1.8, conductivity=2e-3)
+    o.add_object((12, 20, 25, 40, 20, 28), 1.8, kind="absorbing", conductivity=2e-3)
+    src = (nx // 2, ny // 2, nz // 2)
+    g[src] = fdtd.PointSource(period=11)
+    o.add_point_source(src, period=11)
+    return g, o
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("dense", [False, True], ids=["const-materials", "array-materials"])
+@pytest.mark.parametrize("shape,periodic_y", [((26, 70, 66), False), ((24, 150, 30), False),
+                                              ((25, 66, 67), True)])
+def test_large_plane_kernels_against_oracle(shape, periodic_y, dense, dtype):
+    fdtd.set_backend(f"hip.{dtype}")
+    assert shape[1] * shape[2] >= 4096
+    g, o = _build(shape, np.random.RandomState(5), dense, periodic_y)
+    g.run(15, progress_bar=False)
+    o.run(15)
+    torch.cuda.synchronize()
+    found = _lib.load().fdtdhip_plan_scan_materials(g._plan, 1)
+    assert found == (0 if dense else 3), "material scan outcome"
+    assert rel_l2(host(g.E), o.E) <= TOL[dtype]
+    assert rel_l2(host(g.H), o.H) <= TOL[dtype]
+    for b, ob in zip(g.boundaries, o.boundaries):
+        if isinstance(ob, orc.OraclePML):
+            # the two memory variables per field that are ever non-zero
+            u, v = (ob.axis + 1) % 3, (ob.axis + 2) % 3
+            for mine, fam in ((b._psiE, ob.psi_E), (b._psiH, ob.psi_H)):
+                want = np.stack([fam[u][..., ob.axis], fam[v][..., ob.axis]])
+                assert rel_l2(host(mine).reshape(want.shape), want) <= TOL[dtype]
+
+
+def test_material_write_is_noticed():
+    """An in-place write to a scanned material array is seen before the next step."""
+    fdtd.set_backend("hip.float64")
+    shape = (12, 70, 64)
+    g, o = fdtd.Grid(shape), orc.OracleGrid(shape)
+    g[6, 35, 32] = fdtd.PointSource(period=9)
+    o.add_point_source((6, 35, 32), period=9)
+    g.run(6, progress_bar=False); o.run(6)
+    g.inverse_permittivity[5:8, 30:40, 28:36, :] = 0.4
+    o.inverse_permittivity[5:8, 30:40, 28:36, :] = 0.4
+    g.inverse_permeability[4:9, 33:37, 30:34, 1] *= 0.9
+    o.inverse_permeability[4:9, 33:37, 30:34, 1] *= 0.9
+    g.run(6, progress_bar=False); o.run(6)
+    assert rel_l2(host(g.E), o.E) <= 1e-12 and rel_l2(host(g.H), o.H) <= 1e-12
+    # writes torch does not count need the explicit notice
+    g.inverse_permittivity.data[2:4, 10:20, 10:20, :] = 0.7
+    o.inverse_permittivity[2:4, 10:20, 10:20, :] = 0.7
+    g.materials_changed()
+    g.run(4, progress_bar=False); o.run(4)
+    assert rel_l2(host(g.E), o.E) <= 1e-12 and rel_l2(host(g.H), o.H) <= 1e-12
+
+
+def _full_size_grid(n, source, t=10):
+    g = fdtd.Grid((n, n, n))
+    for axis in range(3):
+        lo, hi = [slice(None)] * 3, [slice(None)] * 3
+        lo[axis], hi[axis] = slice(0, t), slice(-t, None)
+        g[tuple(lo)] = fdtd.PML()
+        g[tuple(hi)] = fdtd.PML()
+    g[source] = fdtd.PointSource(period=14)
+    return g
+
+
+def test_full_size_material_paths_agree_bitwise():
+    """512^3 float32 (the benchmark grid): homogeneous materials read as constants and
+    the same arrays read from memory give identical fields."""
+    fdtd.set_backend("hip.float32")
+    n, steps, src = 512, 8, (256, 250, 261)
+    a = _full_size_grid(n, src)
+    a.run(steps, progress_bar=False)
+    lib = _lib.load()
+    assert lib.fdtdhip_plan_scan_materials(a._plan, 1) == 3
+    b = _full_size_grid(n, src)
+    b._ensure_plan()
+    b._material_scans = b._MAX_MATERIAL_SCANS + 1   # keep the arrays in use
+    assert lib.fdtdhip_plan_scan_materials(b._plan, 0) == 0
+    b.run(steps, progress_bar=False)
+    torch.cuda.synchronize()
+    assert float(a.E.abs().max()) > 0
+    assert torch.equal(a.E, b.E) and torch.equal(a.H, b.H)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_full_size_translation_invariance(dtype):
+    """Away from the boundaries the update is the same at every cell: moving the source
+    by whole cells moves the field bit for bit.  The 512^3 x 3 arrays hold 4.0e8
+    elements; in float64 their byte offsets pass 2^31."""
+    fdtd.set_backend(f"hip.{dtype}")
+    n = 512
+    steps, w = 12, 16
+    s1, s2 = (n // 2 - 60, n // 2 - 40, n // 2 - 70), (n // 2 + 90, n // 2 + 75, n // 2 + 101)
+    fields = []
+    for s in (s1, s2):
+        g = _full_size_grid(n, s)
+        g.run(steps, progress_bar=False)
+        win = tuple(slice(c - w, c + w) for c in s)
+        fields.append((g.E[win].clone(), g.H[win].clone()))
+        del g
+        torch.cuda.empty_cache()
+    assert float(fields[0][0].abs().max()) > 0
+    assert torch.equal(fields[0][0], fields[1][0]) and torch.equal(fields[0][1], fields[1][1])

@@ -1,8 +1,9 @@
 // Kernel micro-benchmark for libfdtd_hip: times the bulk half-step kernels through
 // the C ABI on device-resident random data.  Usage:
 //   kbench nx ny nz f32|f64 steps [pml_thickness]
-// Kernel strategy is chosen with the library's FDTDHIP_BULK / FDTDHIP_XCHUNK
-// environment variables.
+// Kernel strategy is chosen with the library's FDTDHIP_BULK environment variable;
+// KB_FUSED=1 provides second buffers so fdtdhip_run may take fused whole steps
+// (FDTDHIP_FUSED=1 forces them on grids of any size).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -51,8 +52,10 @@ void run(int nx, int ny, int nz, int steps, int t) {
   CHECK(hipMalloc(&im, n * sizeof(T)));
   fill<T><<<4096, 256>>>(E, n, 1, (T)-1e-3, (T)1e-3);
   fill<T><<<4096, 256>>>(H, n, 2, (T)-1e-3, (T)1e-3);
-  fill<T><<<4096, 256>>>(ie, n, 3, (T)0.5, (T)1.0);
-  fill<T><<<4096, 256>>>(im, n, 4, (T)0.5, (T)1.0);
+  // KB_UNIFORM=1: homogeneous materials, which fdtdhip_plan_scan_materials turns into constants
+  const bool uniform = getenv("KB_UNIFORM") && atoi(getenv("KB_UNIFORM"));
+  fill<T><<<4096, 256>>>(ie, n, 3, uniform ? (T)1.0 : (T)0.5, (T)1.0);
+  fill<T><<<4096, 256>>>(im, n, 4, uniform ? (T)1.0 : (T)0.5, (T)1.0);
   CHECK(hipDeviceSynchronize());
   fdtdhip_plan* plan;
   const int dtype = sizeof(T) == 4 ? FDTDHIP_F32 : FDTDHIP_F64;
@@ -88,6 +91,8 @@ void run(int nx, int ny, int nz, int steps, int t) {
         }
       }
   }
+  const int found = fdtdhip_plan_scan_materials(plan, uniform ? 1 : 0);
+  LIB(found);
   LIB(fdtdhip_run(plan, 0, 4));
   CHECK(hipDeviceSynchronize());
   LIB(fdtdhip_plan_enable_timing(plan, 1));
@@ -104,12 +109,13 @@ void run(int nx, int ny, int nz, int steps, int t) {
   int64_t nE, nH;
   LIB(fdtdhip_plan_get_timing(plan, &msE, &nE, &msH, &nH));
   const double cells = (double)nx * ny * nz;
-  const double bytes_half = cells * 12 * sizeof(T);
+  // four arrays of three components; a material array found constant is not read
+  const double bytes_half = cells * (found == 3 ? 9 : 12) * sizeof(T);
   const char* strat = getenv("FDTDHIP_BULK");
   if (nH == 0) { nH = 1; msH = 0; }
-  printf("%-8s fused=%d %dx%dx%d %s pml=%d | E %.4f ms %.0f GB/s | H %.4f ms %.0f GB/s | step %.4f ms "
+  printf("%-8s fused=%d const=%d %dx%dx%d %s pml=%d | E %.4f ms %.0f GB/s | H %.4f ms %.0f GB/s | step %.4f ms "
          "%.2f Gcells/s (%.0f GB/s algorithmic)\n",
-         strat ? strat : "default", (int)fused, nx, ny, nz, sizeof(T) == 4 ? "f32" : "f64", t,
+         strat ? strat : "default", (int)fused, found, nx, ny, nz, sizeof(T) == 4 ? "f32" : "f64", t,
          msE / nE, bytes_half / (msE / nE) / 1e6, msH / nH, msH > 0 ? bytes_half / (msH / nH) / 1e6 : 0.0,
          wall / steps, cells * steps / wall / 1e6, 2 * bytes_half * steps / wall / 1e6);
   LIB(fdtdhip_plan_destroy(plan));

@@ -8,9 +8,9 @@ export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 bench.py --no-cpu-baseline "$@" > "$out/bench.log" 2>&1
-tail -1 "$out/bench.log"
+grep "^{\"metric\"" "$out/bench.log" | cut -c1-300
 f=$(find "$out" -name "*kernel_stats.csv" | head -1)
 mkdir -p gpurun_out/profiles_$tag
 cp "$f" gpurun_out/profiles_$tag/kernel_stats.csv
-tail -1 "$out/bench.log" > gpurun_out/profiles_$tag/bench_line.json
+grep "^{\"metric\"" "$out/bench.log" > gpurun_out/profiles_$tag/bench_line.json
 head -8 "$f"
