@@ -247,6 +247,9 @@ def main():
             "materials": {0: "arrays", 1: "inverse permittivity constant", 2: "inverse permeability constant",
                           3: "constants"}[mask],
             "bytes_per_launch": per_launch,
+            # the same duration priced at 12 values per cell and half step whatever the
+            # materials are (every array counted as read): an effective rate, not HBM traffic
+            "all_arrays_equivalent_GBps": round(cells * 12 * es / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
             "avg_launch_ms": round(avg_ms, 4),
             "avg_launch_ms_E": round(ms_e / steps, 4),
             "avg_launch_ms_H": round(ms_h / steps, 4),

@@ -106,19 +106,14 @@ class OracleSlabEngine:
 
     # -- half-step pieces: ranges are recorded, the oracle acts when the step completes
     def bulk_E(self, x0, x1):
-        self.calls.append(("E", x0, x1, self._ghost_ready("E")))
+        self.calls.append(("E", x0, x1))
 
     def bulk_H(self, x0, x1):
-        self.calls.append(("H", x0, x1, self._ghost_ready("H")))
-
-    def _ghost_ready(self, phase):
-        g = self.grid
-        ex = getattr(g, "_test_exchange_done", None)
-        return ex
+        self.calls.append(("H", x0, x1))
 
     def _check_cover(self, phase):
         g = self.grid
-        mine = [(a, b) for p, a, b, _ in self.calls if p == phase and b > a]
+        mine = [(a, b) for p, a, b in self.calls if p == phase and b > a]
         covered = sorted(mine)
         pos = 0
         for a, b in covered:

@@ -104,6 +104,21 @@ def test_slabs_equal_single_grid_gpu(scene_name, tmp_path):
     _check(scene_name, 2, True, tmp_path)
 
 
+@pytest.mark.gpu
+def test_rccl_point_to_point_on_one_gpu():
+    """The transport of the real multi-GPU runs (RCCL send/recv started before the
+    interior kernel, waited for on the stream) exercised on one GPU: a one-rank "nccl"
+    group whose only rank sends a plane to itself (tools/rccl_self_check.py)."""
+    import subprocess
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(slab_support.free_port()))
+    script = os.path.join(os.path.dirname(HERE), "tools", "rccl_self_check.py")
+    done = subprocess.run([sys.executable, "-u", script], env=env, capture_output=True, text=True,
+                          timeout=110)
+    assert done.returncode == 0, done.stdout + done.stderr
+    assert "RCCL self send/recv of a plane: ok" in done.stdout
+
+
 def test_partition_arithmetic():
     from fdtd_amd.parallel import SlabGrid
 
