@@ -50,6 +50,8 @@ PROTOTYPES = {
     "fdtdhip_plan_set_object_grad": (_i, [_p, _i, _p]),
     "fdtdhip_plan_set_pml_adjoint": (_i, [_p, _i, _p, _p]),
     "fdtdhip_adjoint_run": (_i, [_p, _i64, _p, _p, _p]),
+    "fdtdhip_adjoint_cells": (_i, [_p, _i, _i64, _p, _p, _p]),
+    "fdtdhip_adjoint_gather": (_i, [_p, _i, _p, _p, _p, _p]),
     "fdtdhip_plan_enable_timing": (_i, [_p, _i]),
     "fdtdhip_plan_get_timing": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

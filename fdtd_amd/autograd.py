@@ -16,6 +16,11 @@ fdtd/objects.py:315-349).  Here a run of ``n`` steps is a single
 Differentiable inputs: ``grid.E``, ``grid.H``, the PML memory variables (so that
 consecutive runs chain) and ``obj.inverse_permittivity`` of anisotropic objects
 that require grad.  Material arrays of the grid and sources are constants.
+
+On x-slabs (``fdtd_amd.parallel.SlabGrid``) every rank records the same chain of
+nodes for its planes; the reverse sweep exchanges one plane of difference adjoints
+with a neighbour per half step, so ``backward`` is a collective: every rank must
+reach it (``SlabGrid.backward(loss)`` makes sure of that).
 """
 
 import ctypes
@@ -67,11 +72,7 @@ class _Run(torch.autograd.Function):
             _lib.check(lib.fdtdhip_plan_set_object_trace(plan, o._native_id, _ptr(tr), n))
             traces.append(tr)
         try:
-            for det in grid.detectors:
-                det._reserve(lib, plan, n, n)
-            _lib.check(lib.fdtdhip_run(plan, grid.time_steps_passed, n))
-            for det in grid.detectors:
-                det._commit(n, n)
+            grid._native_run(lib, n)
         finally:
             for o in objs:
                 _lib.check(lib.fdtdhip_plan_set_object_trace(plan, o._native_id, None, 0))
@@ -105,7 +106,7 @@ class _Run(torch.autograd.Function):
             _lib.check(lib.fdtdhip_plan_set_pml_adjoint(
                 plan, p._native_id, _ptr(lam_psi[2 * n_p]), _ptr(lam_psi[2 * n_p + 1])))
         try:
-            _lib.check(lib.fdtdhip_adjoint_run(plan, n, _ptr(lamE), _ptr(lamH), _ptr(work)))
+            grid._native_adjoint(lib, n, lamE, lamH, work)
         finally:
             for o in objs:
                 _lib.check(lib.fdtdhip_plan_set_object_trace(plan, o._native_id, None, 0))
@@ -118,8 +119,6 @@ class _Run(torch.autograd.Function):
 def differentiable_advance(grid, n):
     """``n`` full steps recorded as one autograd node; re-binds the grid's state tensors
     to the node's outputs."""
-    if grid.Nx != grid.Nx_global:
-        raise NotImplementedError("differentiable runs are not available on x-slabs")
     objs, pmls = _learnable(grid), _active_pmls(grid)
     grid._fields()
     inputs = [o.inverse_permittivity for o in objs]

@@ -617,12 +617,37 @@ int curl_launch(const void* in, void* out, int nx, int ny, int nz, bool forward,
   return 0;
 }
 
-// One reverse step of the adjoint recursion: undo the H half step, then the E half step
-// (each: reverse of the post pieces, pass 1 per cell, pass 2 gather).
+// The adjoint of one half step is: reverse of the post pieces, pass 1 per cell
+// (adjoint_cells), pass 2 gather (adjoint_gather).  On x-slabs the caller exchanges one
+// plane of `work` with a neighbour rank between the two passes.
 template <typename T>
-int adjoint_half(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
+int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArgs<T>& a) {
+  a.lamF = phaseE ? lamE : lamH;
+  a.lamG = phaseE ? lamH : lamE;
+  a.mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
+  a.work = work;
+  a.nx = p->nx; a.ny = p->ny; a.nz = p->nz;
+  a.sc = (T)p->sc;
+  a.npml = (int)p->pmls.size();
+  a.nobj = phaseE ? (int)p->objs.size() : 0;
+  a.obj = (const ObjK<T>*)p->obj_table;
+  a.trace_step = phaseE ? p->trace_cursor : -1;
+  for (const PmlH& h : p->pmls)
+    if (!(phaseE ? h.lamE : h.lamH)) return fail(-1, "PML adjoint arrays not set");
+  if (int rc = sync_pml_tables<T>(p)) return rc;
+  a.pml = pml_table<T>(p, phaseE ? TAB_ADJ_E : TAB_ADJ_H);
+  a.open_lo = p->H_below ? 1 : 0;
+  a.open_hi = p->E_above ? 1 : 0;
+  a.wghost = nullptr;
+  return 0;
+}
+
+template <typename T>
+int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
+  if (!p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
+  if (!lamE || !lamH || !work) return fail(-1, "null adjoint array");
+  if (int rc = sync_obj_table<T>(p)) return rc;
   T* lamF = phaseE ? lamE : lamH;
-  T* lamG = phaseE ? lamH : lamE;
   const T* mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
   // reverse of post(): sources (hard assignments kill the adjoint), then the boundaries
   // that follow the first periodic one, last first
@@ -660,25 +685,23 @@ int adjoint_half(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
     }
   }
   AdjArgs<T> a;
-  a.lamF = lamF; a.lamG = lamG; a.mat = mat; a.work = work;
-  a.nx = p->nx; a.ny = p->ny; a.nz = p->nz;
-  a.sc = (T)p->sc;
-  a.npml = (int)p->pmls.size();
-  a.nobj = phaseE ? (int)p->objs.size() : 0;
-  a.obj = (const ObjK<T>*)p->obj_table;
-  a.trace_step = phaseE ? p->trace_cursor : -1;
-  for (const PmlH& h : p->pmls)
-    if (!(phaseE ? h.lamE : h.lamH)) return fail(-1, "PML adjoint arrays not set");
-  if (int rc = sync_pml_tables<T>(p)) return rc;
-  a.pml = pml_table<T>(p, phaseE ? TAB_ADJ_E : TAB_ADJ_H);
+  if (int rc = adjoint_args<T>(p, phaseE, lamE, lamH, work, a)) return rc;
   const dim3 grid(blocks_for(p->cells())), block(256);
-  if (phaseE) {
-    hipLaunchKernelGGL((adj_E_cells<T>), grid, block, 0, p->stream, a);
-    hipLaunchKernelGGL((adj_gather<T, true>), grid, block, 0, p->stream, a);
-  } else {
-    hipLaunchKernelGGL((adj_H_cells<T>), grid, block, 0, p->stream, a);
-    hipLaunchKernelGGL((adj_gather<T, false>), grid, block, 0, p->stream, a);
-  }
+  if (phaseE) hipLaunchKernelGGL((adj_E_cells<T>), grid, block, 0, p->stream, a);
+  else hipLaunchKernelGGL((adj_H_cells<T>), grid, block, 0, p->stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int adjoint_gather(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, const T* wghost) {
+  if (!lamE || !lamH || !work) return fail(-1, "null adjoint array");
+  AdjArgs<T> a;
+  if (int rc = adjoint_args<T>(p, phaseE, lamE, lamH, work, a)) return rc;
+  a.wghost = wghost;
+  const dim3 grid(blocks_for(p->cells())), block(256);
+  if (phaseE) hipLaunchKernelGGL((adj_gather<T, true>), grid, block, 0, p->stream, a);
+  else hipLaunchKernelGGL((adj_gather<T, false>), grid, block, 0, p->stream, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -686,12 +709,15 @@ int adjoint_half(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
 template <typename T>
 int adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH, void* work) {
   if (!p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
-  if (p->H_below || p->E_above) return fail(-1, "the adjoint is not available on x-slabs");
-  if (int rc = sync_obj_table<T>(p)) return rc;
+  if (p->H_below || p->E_above)
+    return fail(-1, "x-slabs: drive fdtdhip_adjoint_cells / fdtdhip_adjoint_gather per half step");
   for (int64_t s = nsteps - 1; s >= 0; --s) {
     p->trace_cursor = s;
-    if (int rc = adjoint_half<T>(p, false, (T*)lamE, (T*)lamH, (T*)work)) return rc;
-    if (int rc = adjoint_half<T>(p, true, (T*)lamE, (T*)lamH, (T*)work)) return rc;
+    for (int phase = 0; phase < 2; ++phase) {  // undo the H half step, then the E half step
+      if (int rc = adjoint_cells<T>(p, phase == 1, (T*)lamE, (T*)lamH, (T*)work)) return rc;
+      if (int rc = adjoint_gather<T>(p, phase == 1, (T*)lamE, (T*)lamH, (T*)work, (const T*)nullptr))
+        return rc;
+    }
   }
   p->trace_cursor = -1;
   return 0;
@@ -1149,6 +1175,27 @@ int fdtdhip_adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH,
   DeviceGuard g(p->device);
   return DISPATCH(p, adjoint_run<float>(p, nsteps, lamE, lamH, work),
                   adjoint_run<double>(p, nsteps, lamE, lamH, work));
+}
+
+int fdtdhip_adjoint_cells(fdtdhip_plan* p, int phase_E, int64_t step, void* lamE, void* lamH,
+                          void* work) {
+  if (!p) return fail(-1, "null plan");
+  DeviceGuard g(p->device);
+  p->trace_cursor = step;
+  const int rc = DISPATCH(p, adjoint_cells<float>(p, phase_E != 0, (float*)lamE, (float*)lamH, (float*)work),
+                          adjoint_cells<double>(p, phase_E != 0, (double*)lamE, (double*)lamH, (double*)work));
+  p->trace_cursor = -1;
+  return rc;
+}
+
+int fdtdhip_adjoint_gather(fdtdhip_plan* p, int phase_E, void* lamE, void* lamH, void* work,
+                           const void* work_ghost) {
+  if (!p) return fail(-1, "null plan");
+  DeviceGuard g(p->device);
+  return DISPATCH(p, adjoint_gather<float>(p, phase_E != 0, (float*)lamE, (float*)lamH, (float*)work,
+                                           (const float*)work_ghost),
+                  adjoint_gather<double>(p, phase_E != 0, (double*)lamE, (double*)lamH, (double*)work,
+                                         (const double*)work_ghost));
 }
 
 int fdtdhip_plan_enable_timing(fdtdhip_plan* p, int on) {

@@ -84,6 +84,11 @@ struct AdjArgs {
   const ObjK<T>* obj;
   int64_t trace_step;
   const PmlK<T>* pml;  // device table; psi -> adjoint of the memory variables
+  // x-slabs: the slab continues below plane 0 / above plane nx-1 on a neighbour rank, so the
+  // x differences at that face exist (they read the neighbour's plane in the forward pass)
+  int open_lo, open_hi;
+  const T* wghost;     // pass 2: the neighbour's `work` plane across the face the gather
+                       // reaches over ((ny,nz,6)), or null
 };
 
 }  // namespace fdtdhip

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
   G[WZ_X] += g[1]; G[WX_Z] -= g[1];
   G[WX_Y] += g[2]; G[WY_X] -= g[2];
   // differences the forward pass dropped at the low edges carry no adjoint
-  if (i == 0) G[WX_Y] = G[WX_Z] = 0;
+  if (i == 0 && !a.open_lo) G[WX_Y] = G[WX_Z] = 0;
   if (j == 0) G[WY_X] = G[WY_Z] = 0;
   if (k == 0) G[WZ_X] = G[WZ_Y] = 0;
 
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void adj_H_cells(AdjArgs<T> a) {
   G[WY_Z] += g[0]; G[WZ_Y] -= g[0];
   G[WZ_X] += g[1]; G[WX_Z] -= g[1];
   G[WX_Y] += g[2]; G[WY_X] -= g[2];
-  if (i == a.nx - 1) G[WX_Y] = G[WX_Z] = 0;
+  if (i == a.nx - 1 && !a.open_hi) G[WX_Y] = G[WX_Z] = 0;
   if (j == a.ny - 1) G[WY_X] = G[WY_Z] = 0;
   if (k == a.nz - 1) G[WZ_X] = G[WZ_Y] = 0;
   T* w = a.work + cell * 6;
@@ -178,17 +178,22 @@ __global__ __launch_bounds__(256) void adj_gather(AdjArgs<T> a) {
   const T* w = a.work + cell * 6;
   const int64_t sx = plane * 6, sy = (int64_t)a.nz * 6, sz = 6;
   auto nb = [&](bool ok, int64_t off, int which) { return ok ? w[off + which] : T(0); };
+  // x neighbour: inside the slab, or the neighbour rank's plane, or nothing at a domain edge
+  auto nbx = [&](bool inside, int64_t off, bool open, int which) {
+    if (inside) return w[off + which];
+    return open && a.wghost ? a.wghost[r * 6 + which] : T(0);
+  };
   T add[3];
   if (PHASE_E) {
     const bool ox = i < a.nx - 1, oy = j < a.ny - 1, oz = k < a.nz - 1;
     add[0] = (w[WY_X] - nb(oy, sy, WY_X)) + (w[WZ_X] - nb(oz, sz, WZ_X));
-    add[1] = (w[WX_Y] - nb(ox, sx, WX_Y)) + (w[WZ_Y] - nb(oz, sz, WZ_Y));
-    add[2] = (w[WX_Z] - nb(ox, sx, WX_Z)) + (w[WY_Z] - nb(oy, sy, WY_Z));
+    add[1] = (w[WX_Y] - nbx(ox, sx, a.open_hi, WX_Y)) + (w[WZ_Y] - nb(oz, sz, WZ_Y));
+    add[2] = (w[WX_Z] - nbx(ox, sx, a.open_hi, WX_Z)) + (w[WY_Z] - nb(oy, sy, WY_Z));
   } else {
     const bool ox = i > 0, oy = j > 0, oz = k > 0;
     add[0] = (nb(oy, -sy, WY_X) - w[WY_X]) + (nb(oz, -sz, WZ_X) - w[WZ_X]);
-    add[1] = (nb(ox, -sx, WX_Y) - w[WX_Y]) + (nb(oz, -sz, WZ_Y) - w[WZ_Y]);
-    add[2] = (nb(ox, -sx, WX_Z) - w[WX_Z]) + (nb(oy, -sy, WY_Z) - w[WY_Z]);
+    add[1] = (nbx(ox, -sx, a.open_lo, WX_Y) - w[WX_Y]) + (nb(oz, -sz, WZ_Y) - w[WZ_Y]);
+    add[2] = (nbx(ox, -sx, a.open_lo, WX_Z) - w[WX_Z]) + (nb(oy, -sy, WY_Z) - w[WY_Z]);
   }
   T* out = a.lamG + cell * 3;
   out[0] += add[0];

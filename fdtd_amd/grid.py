@@ -360,12 +360,22 @@ class Grid:
         if n >= 2:
             self._provide_step_buffers()
         lib = self._ensure_plan()
+        self._native_run(lib, n)
+        self.time_steps_passed += n
+
+    def _native_run(self, lib, n):
+        """``n`` full steps from ``time_steps_passed`` on the prepared plan (the counter is
+        advanced by the caller)."""
         for det in self.detectors:
             det._reserve(lib, self._plan, n, n)
         _lib.check(lib.fdtdhip_run(self._plan, self.time_steps_passed, n))
         for det in self.detectors:
             det._commit(n, n)
-        self.time_steps_passed += n
+
+    def _native_adjoint(self, lib, n, lamE, lamH, work):
+        """Reverse sweep over the last ``n`` steps (see ``fdtd_amd/autograd.py``)."""
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        _lib.check(lib.fdtdhip_adjoint_run(self._plan, n, p(lamE), p(lamH), p(work)))
 
     def _provide_step_buffers(self):
         """Second E/H (and PML psi_E) buffers that let ``run`` use the fused full-step

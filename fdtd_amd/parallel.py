@@ -175,6 +175,7 @@ class SlabGrid(Grid):
         eng.post_H(q)
 
     def update_E(self):
+        self._no_half_step_autograd()
         eng = self._engine
         eng.prepare()
         eng.reserve_detectors(1, 0)
@@ -182,6 +183,7 @@ class SlabGrid(Grid):
         eng.commit_detectors(1, 0)
 
     def update_H(self):
+        self._no_half_step_autograd()
         eng = self._engine
         eng.prepare()
         eng.reserve_detectors(0, 1)
@@ -191,6 +193,15 @@ class SlabGrid(Grid):
     def _advance(self, n):
         if n <= 0:
             return
+        from . import autograd
+
+        if not bd.staging and autograd.needs_grad(self):
+            autograd.differentiable_advance(self, n)
+            return
+        self._native_run(None, n)
+        self.time_steps_passed += n
+
+    def _native_run(self, lib, n):
         eng = self._engine
         eng.prepare()
         eng.reserve_detectors(n, n)
@@ -199,7 +210,41 @@ class SlabGrid(Grid):
             self._half_step_E(eng, q)
             self._half_step_H(eng, q)
         eng.commit_detectors(n, n)
-        self.time_steps_passed += n
+
+    # ----------------------------------------------------------------- adjoint
+    def _native_adjoint(self, lib, n, lamE, lamH, work):
+        """Reverse sweep on a slab.  The forward x differences across a slab face read the
+        neighbour's plane, so their adjoints flow back across it: undoing the H half step,
+        plane 0 gathers from the LAST plane of difference adjoints of the rank below;
+        undoing the E half step, the last plane gathers from the FIRST plane of the rank
+        above.  One ``(Ny, Nz, 6)`` plane per half step and neighbour, as in the forward
+        pass."""
+        r, p, plan = self._rank, self._world, self._plan
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        planes = work.view(self.Nx, self.Ny, self.Nz, 6)
+        from_below = bd.zeros((self.Ny, self.Nz, 6)) if r > 0 else None
+        from_above = bd.zeros((self.Ny, self.Nz, 6)) if r < p - 1 else None
+        for s in range(n - 1, -1, -1):
+            _lib.check(lib.fdtdhip_adjoint_cells(plan, 0, s, ptr(lamE), ptr(lamH), ptr(work)))
+            ex = self._start_exchange(planes[-1] if r < p - 1 else None, r + 1, from_below, r - 1)
+            if ex is not None:
+                ex.wait()
+            _lib.check(lib.fdtdhip_adjoint_gather(plan, 0, ptr(lamE), ptr(lamH), ptr(work),
+                                                  ptr(from_below)))
+            _lib.check(lib.fdtdhip_adjoint_cells(plan, 1, s, ptr(lamE), ptr(lamH), ptr(work)))
+            ex = self._start_exchange(planes[0] if r > 0 else None, r - 1, from_above, r + 1)
+            if ex is not None:
+                ex.wait()
+            _lib.check(lib.fdtdhip_adjoint_gather(plan, 1, ptr(lamE), ptr(lamH), ptr(work),
+                                                  ptr(from_above)))
+
+    def backward(self, loss):
+        """Back-propagate this rank's part of the loss (the total loss is the sum over
+        ranks).  Collective: the reverse sweep exchanges planes with the neighbours, so
+        every rank calls it, also one whose part of the loss does not depend on the
+        fields -- the zero-weight term below ties every rank's loss to its slab."""
+        anchor = 0.0 * (self.E.sum() + self.H.sum())
+        (loss + anchor).backward()
 
     def run(self, total_time, progress_bar: bool = False):
         if isinstance(total_time, float):

@@ -192,6 +192,25 @@ int fdtdhip_plan_set_object_grad(fdtdhip_plan* plan, int id, void* grad);
 int fdtdhip_plan_set_pml_adjoint(fdtdhip_plan* plan, int id, void* lam_psiE, void* lam_psiH);
 int fdtdhip_adjoint_run(fdtdhip_plan* plan, int64_t nsteps, void* lamE, void* lamH, void* work);
 
+/* The same reverse sweep in pieces, for x-slabs (fdtdhip_plan_set_halo tells the plan on
+ * which sides the slab continues).  The adjoint of one half step is
+ *   fdtdhip_adjoint_cells  : reverse of the post pieces, then per cell the adjoint of
+ *                            everything that followed the six neighbour differences ->
+ *                            work[cell][6]; `step` is the row of the curl traces to use;
+ *   fdtdhip_adjoint_gather : transpose of the difference stencil, added to the adjoint of
+ *                            the driving field.  The differences across an x face between
+ *                            slabs (reference fdtd/grid.py:46,48,71,73) make the gather reach
+ *                            into the neighbour's `work`: for the E half step (phase_E = 1)
+ *                            `work_ghost` is the FIRST work plane of the rank above, for the
+ *                            H half step the LAST work plane of the rank below, each a
+ *                            contiguous (ny, nz, 6) block exchanged by the caller between
+ *                            the two calls; NULL where the slab ends at a domain edge.
+ * A reverse step undoes the H half step first (phase_E = 0), then the E half step. */
+int fdtdhip_adjoint_cells(fdtdhip_plan* plan, int phase_E, int64_t step, void* lamE, void* lamH,
+                          void* work);
+int fdtdhip_adjoint_gather(fdtdhip_plan* plan, int phase_E, void* lamE, void* lamH, void* work,
+                           const void* work_ghost);
+
 /* Optional: prove that the material arrays need not be read.  The reference fills
  * inverse_permittivity and inverse_permeability with one value (fdtd/grid.py:135-151)
  * and an object zeroes the inverse permittivity in its box (fdtd/objects.py:90), so
