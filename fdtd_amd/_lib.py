@@ -14,6 +14,7 @@ F32, F64 = 0, 1
 OBJ_ISOTROPIC, OBJ_ABSORBING, OBJ_ANISOTROPIC = 0, 1, 2
 SRC_ADD_POINTS, SRC_SET_BOX = 0, 1
 DET_CELLS, DET_CURRENT = 0, 1
+PERIODIC_X_EXTERNAL = 3
 ABI_VERSION = 1
 
 _p, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
@@ -45,6 +46,8 @@ PROTOTYPES = {
     "fdtdhip_update_E_post": (_i, [_p, _i64]),
     "fdtdhip_update_H_bulk": (_i, [_p, _i, _i]),
     "fdtdhip_update_H_post": (_i, [_p, _i64]),
+    "fdtdhip_update_E_post_stage": (_i, [_p, _i64, _i]),
+    "fdtdhip_update_H_post_stage": (_i, [_p, _i64, _i]),
     "fdtdhip_run": (_i, [_p, _i64, _i64]),
     "fdtdhip_plan_set_object_trace": (_i, [_p, _i, _p, _i64]),
     "fdtdhip_plan_set_object_grad": (_i, [_p, _i, _p]),

@@ -98,11 +98,6 @@ class PeriodicBoundary(Boundary):
                 if taken:
                     grid.boundaries.remove(self)
                     raise AttributeError(f"grid already has an {letter}low/{letter}high boundary!")
-                if axis == 0 and grid.Nx != grid.Nx_global:
-                    grid.boundaries.remove(self)
-                    raise NotImplementedError(
-                        "a periodic boundary along x is not available on an x-slab "
-                        "decomposed grid")
                 for a in attrs:
                     setattr(grid, a, self)
                 self.__class__ = _PERIODIC_CLASSES[axis]
@@ -117,7 +112,12 @@ class PeriodicBoundary(Boundary):
         return ("periodic", id(self), self.axis)
 
     def _native_add(self, lib, plan):
-        _lib.check(lib.fdtdhip_plan_add_periodic(plan, self.axis))
+        axis = self.axis
+        if axis == 0 and self.grid.Nx != self.grid.Nx_global:
+            # the two planes live on the first and the last slab: the grid copies them
+            # between ranks (fdtd_amd/parallel.py), the plan only keeps the place in the list
+            axis = _lib.PERIODIC_X_EXTERNAL
+        _lib.check(lib.fdtdhip_plan_add_periodic(plan, axis))
 
 
 class _PeriodicBoundaryX(PeriodicBoundary):

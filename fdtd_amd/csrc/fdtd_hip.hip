@@ -528,7 +528,8 @@ double waveform(const SourceH& s, int64_t q) {
 enum { POST_BOUNDARIES = 1, POST_SOURCES = 2, POST_FINISH = 4, POST_ALL = 7 };
 
 template <typename T>
-int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 = 0, int x1 = -1) {
+int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 = 0, int x1 = -1,
+         int stage = -1) {
   T* F = (T*)(phaseE ? p->E : p->H);
   const T* mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
   if (!F || !mat) return fail(-1, "fields not set");
@@ -540,12 +541,25 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
     for (const ObjH& o : p->objs)
       if (o.trace && p->trace_cursor >= o.trace_capacity) p->trace_cursor = -1;  // traces full
   }
+  // stage 0 / 1: only what precedes / follows the x-periodic boundary whose copy crosses
+  // ranks (the caller performs it in between); sources and the rest belong to stage 1
+  size_t ext = p->boundaries.size();
+  for (size_t n = 0; n < p->boundaries.size(); ++n)
+    if (p->boundaries[n].kind == 1 && p->boundaries[n].idx == FDTDHIP_PERIODIC_X_EXTERNAL) {
+      ext = n;
+      break;
+    }
+  if (stage >= 0 && ext == p->boundaries.size()) return fail(-1, "no external periodic boundary");
+  if (stage == 0) parts &= POST_BOUNDARIES;
   // boundaries that follow the first periodic one, in list order
   bool seen_periodic = false;
-  for (const BoundaryRef& b : p->boundaries) {
+  for (size_t n = 0; n < p->boundaries.size(); ++n) {
+    const BoundaryRef& b = p->boundaries[n];
     if (!(parts & POST_BOUNDARIES)) break;
+    const bool active = stage < 0 || (stage == 0 ? n < ext : n > ext);
     if (b.kind == 1) {
       seen_periodic = true;
+      if (!active || b.idx == FDTDHIP_PERIODIC_X_EXTERNAL) continue;
       const int axis = b.idx;
       const int n = axis == 0 ? p->nx : (axis == 1 ? p->ny : p->nz);
       if (n < 2) continue;  // copy of a plane onto itself
@@ -553,7 +567,7 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
       const int dst = phaseE ? 0 : n - 1, src = phaseE ? n - 1 : 0;
       hipLaunchKernelGGL((periodic_copy<T>), dim3(blocks_for(total)), dim3(256), 0, p->stream, F,
                          p->nx, p->ny, p->nz, axis, dst, src);
-    } else if (seen_periodic) {
+    } else if (seen_periodic && active) {
       const PmlH& h = p->pmls[b.idx];
       PmlK<T> k = make_pmlk<T>(p, h, phaseE);
       const int64_t slab = (int64_t)(h.axis == 0 ? h.t : p->nx) * k.sy * k.sz;
@@ -663,7 +677,11 @@ int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
   }
   size_t first_periodic = p->boundaries.size();
   for (size_t b = 0; b < p->boundaries.size(); ++b)
-    if (p->boundaries[b].kind == 1) { first_periodic = b; break; }
+    if (p->boundaries[b].kind == 1) {
+      if (p->boundaries[b].idx == FDTDHIP_PERIODIC_X_EXTERNAL)
+        return fail(-1, "the adjoint does not cover a periodic boundary that crosses ranks");
+      if (first_periodic == p->boundaries.size()) first_periodic = b;
+    }
   for (size_t b = p->boundaries.size(); b-- > first_periodic;) {
     const BoundaryRef& br = p->boundaries[b];
     if (br.kind == 1) {
@@ -966,7 +984,10 @@ int fdtdhip_plan_add_pml(fdtdhip_plan* p, int axis, int side, int t, const doubl
 
 int fdtdhip_plan_add_periodic(fdtdhip_plan* p, int axis) {
   if (!p) return fail(-1, "null plan");
-  if (axis < 0 || axis > 2) return fail(-1, "bad axis");
+  if (axis < 0 || axis > FDTDHIP_PERIODIC_X_EXTERNAL) return fail(-1, "bad axis");
+  if (axis == FDTDHIP_PERIODIC_X_EXTERNAL)
+    for (const BoundaryRef& b : p->boundaries)
+      if (b.kind == 1 && b.idx == axis) return fail(-1, "one external periodic boundary at most");
   p->boundaries.push_back({1, axis});
   return 0;
 }
@@ -1105,6 +1126,20 @@ int fdtdhip_update_H_post(fdtdhip_plan* p, int64_t q) {
   if (!p) return fail(-1, "null plan");
   DeviceGuard g(p->device);
   return DISPATCH(p, post<float>(p, false, q), post<double>(p, false, q));
+}
+int fdtdhip_update_E_post_stage(fdtdhip_plan* p, int64_t q, int stage) {
+  if (!p) return fail(-1, "null plan");
+  if (stage != 0 && stage != 1) return fail(-1, "stage is 0 or 1");
+  DeviceGuard g(p->device);
+  return DISPATCH(p, post<float>(p, true, q, POST_ALL, 0, -1, stage),
+                  post<double>(p, true, q, POST_ALL, 0, -1, stage));
+}
+int fdtdhip_update_H_post_stage(fdtdhip_plan* p, int64_t q, int stage) {
+  if (!p) return fail(-1, "null plan");
+  if (stage != 0 && stage != 1) return fail(-1, "stage is 0 or 1");
+  DeviceGuard g(p->device);
+  return DISPATCH(p, post<float>(p, false, q, POST_ALL, 0, -1, stage),
+                  post<double>(p, false, q, POST_ALL, 0, -1, stage));
 }
 
 int fdtdhip_update_E(fdtdhip_plan* p, int64_t q) {

@@ -64,6 +64,12 @@ class _NativeEngine:
     def post_H(self, q):
         _lib.check(self.lib.fdtdhip_update_H_post(self.plan, q))
 
+    def post_E_stage(self, q, stage):
+        _lib.check(self.lib.fdtdhip_update_E_post_stage(self.plan, q, stage))
+
+    def post_H_stage(self, q, stage):
+        _lib.check(self.lib.fdtdhip_update_H_post_stage(self.plan, q, stage))
+
 
 class _Exchange:
     """One in-flight neighbour exchange (send one plane, receive one plane)."""
@@ -128,6 +134,12 @@ class SlabGrid(Grid):
             dist.broadcast(buf, src=self._global_rank(last), group=self._group)
         return buf
 
+    @property
+    def _x_wrap(self):
+        """A periodic boundary along x on a grid of several slabs."""
+        return self._world > 1 and any(
+            getattr(b, "axis", None) == 0 and not hasattr(b, "thickness") for b in self.boundaries)
+
     # ------------------------------------------------------------ halo exchange
     def _start_exchange(self, send, dst, recv, src):
         """Send plane ``send`` to rank ``dst`` and receive into ``recv`` from rank ``src``
@@ -160,7 +172,17 @@ class SlabGrid(Grid):
             ex.wait()
         if first:
             eng.bulk_E(0, 1)             # the plane that reads H_below
-        eng.post_E(q)
+        if self._x_wrap:
+            # E[0] = E[-1] of the whole simulation (reference fdtd/boundaries.py:177),
+            # at its place among the boundaries
+            eng.post_E_stage(q, 0)
+            ex = self._start_exchange(self.E[-1] if r == p - 1 else None, 0,
+                                      self.E[0] if r == 0 else None, p - 1)
+            if ex is not None:
+                ex.wait()
+            eng.post_E_stage(q, 1)
+        else:
+            eng.post_E(q)
 
     def _half_step_H(self, eng, q):
         r, p = self._rank, self._world
@@ -172,7 +194,16 @@ class SlabGrid(Grid):
             ex.wait()
         if last < self.Nx:
             eng.bulk_H(last, self.Nx)    # the plane that reads E_above
-        eng.post_H(q)
+        if self._x_wrap:
+            # H[-1] = H[0] of the whole simulation (reference fdtd/boundaries.py:182)
+            eng.post_H_stage(q, 0)
+            ex = self._start_exchange(self.H[0] if r == 0 else None, p - 1,
+                                      self.H[-1] if r == p - 1 else None, 0)
+            if ex is not None:
+                ex.wait()
+            eng.post_H_stage(q, 1)
+        else:
+            eng.post_H(q)
 
     def update_E(self):
         self._no_half_step_autograd()

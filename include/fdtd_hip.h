@@ -101,7 +101,9 @@ int fdtdhip_plan_add_pml(fdtdhip_plan* plan, int axis, int side, int thickness,
                          const double* bE, const double* cE, const double* bH,
                          const double* cH, void* psiE, void* psiH);
 
-/* Periodic boundary along `axis` (reference fdtd/boundaries.py:173-208). */
+/* Periodic boundary along `axis` (reference fdtd/boundaries.py:173-208); axis may be
+ * FDTDHIP_PERIODIC_X_EXTERNAL (see fdtdhip_update_E_post_stage). */
+#define FDTDHIP_PERIODIC_X_EXTERNAL 3
 int fdtdhip_plan_add_periodic(fdtdhip_plan* plan, int axis);
 
 /* Object occupying box = {x0,x1,y0,y1,z0,z1} (reference fdtd/objects.py:116-126,
@@ -155,6 +157,17 @@ int fdtdhip_update_E_bulk(fdtdhip_plan* plan, int x0, int x1);
 int fdtdhip_update_E_post(fdtdhip_plan* plan, int64_t q);
 int fdtdhip_update_H_bulk(fdtdhip_plan* plan, int x0, int x1);
 int fdtdhip_update_H_post(fdtdhip_plan* plan, int64_t q);
+
+/* x-periodic boundary of an x-slab decomposition (reference fdtd/boundaries.py:173-184:
+ * E[0] = E[-1] after the E update, H[-1] = H[0] after the H update): the two planes
+ * live on the first and the last rank, so the copy is the caller's (a plane sent
+ * between the two ranks).  Registered with fdtdhip_plan_add_periodic(plan,
+ * FDTDHIP_PERIODIC_X_EXTERNAL) at its place in the boundary list -- later PMLs apply
+ * their correction after it, as after any periodic boundary -- it makes the post
+ * pieces come in two stages: stage 0 = the boundaries before it, [caller's copy],
+ * stage 1 = the boundaries after it, sources, detectors. */
+int fdtdhip_update_E_post_stage(fdtdhip_plan* plan, int64_t q, int stage);
+int fdtdhip_update_H_post_stage(fdtdhip_plan* plan, int64_t q, int stage);
 
 /* Second buffers for the fused full step (no reference counterpart: the reference
  * always runs the two half steps as separate passes, fdtd/grid.py:267-273).  When

@@ -212,6 +212,22 @@ SLAB_SCENES = {
         ],
         steps=30,
     ),
+    # periodic along x: the two planes of the copy sit on the first and the last slab
+    "slab_xperiodic": dict(
+        grid=dict(shape=(25, 13, 11)),
+        items=[
+            ("pml",       (S(None), S(None), S(0, 3)), {}),              # before the periodic one: fused
+            ("periodic",  (0, S(None), S(None)), {}),
+            ("pml",       (S(None), S(-4, None), S(None)), {}),          # after it: applied after the copy
+            ("pml",       (S(None), S(0, 3), S(None)), {}),
+            ("object",    (S(0, 7), S(4, 9), S(2, 8)), dict(permittivity=2.0)),
+            ("absorbing", (S(20, 25), S(3, 8), S(4, 9)), dict(permittivity=1.6, conductivity=2e4)),
+            ("point",     (1, 6, 5), dict(period=9)),
+            ("point",     (23, 7, 6), dict(period=7, amplitude=0.7)),
+            ("linedet",   (S(0, 25), 6, 5), {}),
+        ],
+        steps=36,
+    ),
     "slab_2d": dict(
         grid=dict(shape=(31, 17, 1)),
         items=[

@@ -37,10 +37,13 @@ class OracleSlabEngine:
         og.inverse_permittivity = g.inverse_permittivity.numpy()
         og.inverse_permeability = g.inverse_permeability.numpy()
         self.dets = []
+        self.ext = None   # place of a cross-rank x-periodic boundary in og.boundaries
         for b in g.boundaries:
             if hasattr(b, "thickness"):
                 if b._active:
                     og.add_pml(b.axis, b.side, b.thickness, b.a)
+            elif b.axis == 0 and g.Nx != g.Nx_global:
+                self.ext = len(og.boundaries)
             else:
                 og.add_periodic(b.axis)
         for o in g.objects:
@@ -140,6 +143,48 @@ class OracleSlabEngine:
         og.time_steps_passed = q
         og.halo_hi_E = g._E_above.numpy() if g._E_above is not None else None
         og.update_H()
+
+    # -- the same half steps cut at the cross-rank periodic boundary (the statements of
+    #    OracleGrid.update_E / update_H, reference fdtd/grid.py:275-325)
+    def post_E_stage(self, q, stage):
+        g, og, k = self.grid, self.og, self.ext
+        if stage == 0:
+            self._check_cover("E")
+            og.time_steps_passed = q
+            for b in og.boundaries:
+                b.update_phi_E()
+            curl = orc.curl_H(og.H, g._H_below.numpy() if g._H_below is not None else None)
+            og.E += og.courant_number * og.inverse_permittivity * curl
+            for o in og.objects:
+                o.update_E(curl)
+            for b in og.boundaries[:k]:
+                b.update_E()
+        else:
+            for b in og.boundaries[k:]:
+                b.update_E()
+            for s in og.sources:
+                s.update_E()
+            for d in og.detectors:
+                d.detect_E()
+
+    def post_H_stage(self, q, stage):
+        g, og, k = self.grid, self.og, self.ext
+        if stage == 0:
+            self._check_cover("H")
+            og.time_steps_passed = q
+            for b in og.boundaries:
+                b.update_phi_H()
+            curl = orc.curl_E(og.E, g._E_above.numpy() if g._E_above is not None else None)
+            og.H -= og.courant_number * og.inverse_permeability * curl
+            for b in og.boundaries[:k]:
+                b.update_H()
+        else:
+            for b in og.boundaries[k:]:
+                b.update_H()
+            for s in og.sources:
+                s.update_H()
+            for d in og.detectors:
+                d.detect_H()
 
 
 def free_port():
