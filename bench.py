@@ -12,6 +12,8 @@ Workloads (all synthetic, fields start at zero, a point source drives them):
   m3    512^3 float32, 6 PML(10), anisotropic + absorbing objects, 3 LineDetectors
   m2    256^3 float64, 6 PML(10), PointSource
   c1    161x97x1 float64, the reference's README example
+  m4    256x1024x1024 float32 per GPU, 6 PML(10), PointSource: with --gpus 8 the
+        2048x1024x1024 x-slab configuration
 With --gpus N > 1 the grid is N slabs of the single-GPU size along x (weak
 scaling), one process per GPU, halo planes exchanged over RCCL.
 
@@ -50,6 +52,9 @@ def build_workload(fdtd, name, n_slabs=1, rank=0):
     if name in ("m3v", "m3"):
         fdtd.set_backend("hip.float32")
         shape, es, dt = (512, 512, 512), 4, "f32"
+    elif name == "m4":
+        fdtd.set_backend("hip.float32")
+        shape, es, dt = (256, 1024, 1024), 4, "f32"
     elif name == "m2":
         fdtd.set_backend("hip.float64")
         shape, es, dt = (256, 256, 256), 8, "f64"
@@ -69,7 +74,7 @@ def build_workload(fdtd, name, n_slabs=1, rank=0):
     if name == "m3v":
         grid[nx // 2, ny // 2, nz // 2] = fdtd.PointSource(period=20)
         desc += " vacuum + PointSource"
-    elif name == "m2":
+    elif name in ("m2", "m4"):
         for key in ((slice(0, 10),), (slice(-10, None),), (slice(None), slice(0, 10)),
                     (slice(None), slice(-10, None)), (slice(None), slice(None), slice(0, 10)),
                     (slice(None), slice(None), slice(-10, None))):
@@ -157,7 +162,7 @@ def cpu_baseline(name, budget_s=15.0):
     else:
         n, shape = 128, (128, 128, 128)
     g = OracleGrid(shape)
-    if name in ("m2", "m3"):
+    if name in ("m2", "m3", "m4"):
         for axis in range(3):
             g.add_pml(axis, "low", 10)
             g.add_pml(axis, "high", 10)
