@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfdtd_hip.so")
 
 F32, F64 = 0, 1
-OBJ_ISOTROPIC, OBJ_ABSORBING, OBJ_ANISOTROPIC = 0, 1, 2
+OBJ_ISOTROPIC, OBJ_ABSORBING, OBJ_ANISOTROPIC, OBJ_ANISOTROPIC_MODULATED = 0, 1, 2, 3
 SRC_ADD_POINTS, SRC_SET_BOX = 0, 1
 DET_CELLS, DET_CURRENT = 0, 1
 PERIODIC_X_EXTERNAL = 3
@@ -51,6 +51,7 @@ PROTOTYPES = {
     "fdtdhip_run": (_i, [_p, _i64, _i64]),
     "fdtdhip_plan_set_object_trace": (_i, [_p, _i, _p, _i64]),
     "fdtdhip_plan_set_object_grad": (_i, [_p, _i, _p]),
+    "fdtdhip_plan_set_object_modifier": (_i, [_p, _i, _p, _p, _p]),
     "fdtdhip_plan_set_pml_adjoint": (_i, [_p, _i, _p, _p]),
     "fdtdhip_adjoint_run": (_i, [_p, _i64, _p, _p, _p]),
     "fdtdhip_adjoint_cells": (_i, [_p, _i, _i64, _p, _p, _p]),

@@ -33,8 +33,13 @@ from .backend import backend as bd
 
 def _learnable(grid):
     return [o for o in grid.objects
-            if o._native_kind == _lib.OBJ_ANISOTROPIC and o.Nx > 0
+            if o._native_kind in (_lib.OBJ_ANISOTROPIC, _lib.OBJ_ANISOTROPIC_MODULATED) and o.Nx > 0
             and torch.is_tensor(o.inverse_permittivity) and o.inverse_permittivity.requires_grad]
+
+
+def _modulated(objs):
+    """Those of ``objs`` whose tensor is scaled by the energy-dependent modifier."""
+    return [o for o in objs if o._native_kind == _lib.OBJ_ANISOTROPIC_MODULATED]
 
 
 def _active_pmls(grid):
@@ -58,7 +63,8 @@ class _Run(torch.autograd.Function):
     @staticmethod
     def forward(ctx, grid, n, E, H, *rest):
         objs, pmls = _learnable(grid), _active_pmls(grid)
-        k = len(objs)
+        mods = _modulated(objs)
+        k = len(objs) + 2 * len(mods)   # object tensors, then (weight, bias) per modulated object
         # the run works on fresh state tensors; the inputs keep their values for autograd
         grid.E, grid.H = E.detach().clone(), H.detach().clone()
         psis = [t.detach().clone() for t in rest[k:]]
@@ -66,25 +72,36 @@ class _Run(torch.autograd.Function):
             p._psiE, p._psiH = psis[2 * n_p], psis[2 * n_p + 1]
         lib = grid._ensure_plan()
         plan = grid._plan
-        traces = []
+        traces, etraces = [], []
         for o in objs:
             tr = bd.zeros((n, o.Nx * o.Ny * o.Nz, 3))
             _lib.check(lib.fdtdhip_plan_set_object_trace(plan, o._native_id, _ptr(tr), n))
             traces.append(tr)
+        for o in mods:
+            et = bd.zeros((n, o.Nx * o.Ny * o.Nz, 2))
+            o._mod_buffers = (et, None)
+            o._native_refresh(lib, plan)
+            etraces.append(et)
         try:
             grid._native_run(lib, n)
         finally:
             for o in objs:
                 _lib.check(lib.fdtdhip_plan_set_object_trace(plan, o._native_id, None, 0))
-        ctx.grid, ctx.n, ctx.k, ctx.traces = grid, n, k, traces
+            for o in mods:
+                o._mod_buffers = (None, None)
+                o._native_refresh(lib, plan)
+        ctx.grid, ctx.n, ctx.k, ctx.traces, ctx.etraces = grid, n, k, traces, etraces
+        ctx.mods = mods
+        # weights as they were during this run (an optimiser may change them before backward)
+        ctx.mod_weights = [o._packed_weights().clone() for o in mods]
         ctx.objs, ctx.pmls = objs, pmls
-        ctx.save_for_backward(*rest[:k])
+        ctx.save_for_backward(*rest[:len(objs)])
         return (grid.E, grid.H, *psis)
 
     @staticmethod
     def backward(ctx, gE, gH, *gpsi):
-        grid, n, objs, pmls = ctx.grid, ctx.n, ctx.objs, ctx.pmls
-        params = ctx.saved_tensors
+        grid, n, objs, pmls, mods = ctx.grid, ctx.n, ctx.objs, ctx.pmls, ctx.mods
+        params = ctx.saved_tensors[:len(objs)]
         full = (grid.Nx, grid.Ny, grid.Nz, 3)
 
         def start(g, shape):
@@ -105,15 +122,30 @@ class _Run(torch.autograd.Function):
         for n_p, p in enumerate(pmls):
             _lib.check(lib.fdtdhip_plan_set_pml_adjoint(
                 plan, p._native_id, _ptr(lam_psi[2 * n_p]), _ptr(lam_psi[2 * n_p + 1])))
+        gmods = []
+        for o, et, wb in zip(mods, ctx.etraces, ctx.mod_weights):
+            gm = bd.zeros((o.Nx * o.Ny * o.Nz, 9, 3))
+            _lib.check(lib.fdtdhip_plan_set_object_modifier(plan, o._native_id, _ptr(wb), _ptr(et),
+                                                            _ptr(gm)))
+            gmods.append(gm)
         try:
             grid._native_adjoint(lib, n, lamE, lamH, work)
         finally:
             for o in objs:
                 _lib.check(lib.fdtdhip_plan_set_object_trace(plan, o._native_id, None, 0))
                 _lib.check(lib.fdtdhip_plan_set_object_grad(plan, o._native_id, None))
+            for o in mods:
+                o._weights_key = None
+                o._native_refresh(lib, plan)
             for p in pmls:
                 _lib.check(lib.fdtdhip_plan_set_pml_adjoint(plan, p._native_id, None, None))
-        return (None, None, lamE, lamH, *grads, *lam_psi)
+        wgrads = []
+        for o, gm in zip(mods, gmods):
+            total = gm.sum(0)                       # (9, 3): d/dw_E, d/dw_H, d/dbias per entry
+            w, b = o.nonlin_conv.weight, o.nonlin_conv.bias
+            wgrads.append(total[:, :2].reshape(w.shape).to(w.dtype))
+            wgrads.append(total[:, 2].reshape(b.shape).to(b.dtype))
+        return (None, None, lamE, lamH, *grads, *wgrads, *lam_psi)
 
 
 def differentiable_advance(grid, n):
@@ -122,6 +154,8 @@ def differentiable_advance(grid, n):
     objs, pmls = _learnable(grid), _active_pmls(grid)
     grid._fields()
     inputs = [o.inverse_permittivity for o in objs]
+    for o in _modulated(objs):
+        inputs += [o.nonlin_conv.weight, o.nonlin_conv.bias]
     for p in pmls:
         inputs += [p._psiE, p._psiH]
     out = _Run.apply(grid, n, grid.E, grid.H, *inputs)

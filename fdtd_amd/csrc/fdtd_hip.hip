@@ -74,6 +74,9 @@ struct ObjH {
   void* trace = nullptr;       // (capacity, box, 3) curl trace of a differentiable run
   int64_t trace_capacity = 0;
   void* grad = nullptr;        // gradient accumulator for `inv`
+  const void* modw = nullptr;  // kind 3: (9,3) modifier weights
+  void* etrace = nullptr;      // kind 3: (capacity, box, 2) energy trace
+  void* gmod = nullptr;        // kind 3: (box,9,3) gradient contributions to modw
 };
 
 struct SourceH {
@@ -188,6 +191,9 @@ int sync_obj_table(fdtdhip_plan* p) {
     tab[o].absorb = (const T*)h.absorb;
     tab[o].trace = (T*)h.trace;
     tab[o].grad = (T*)h.grad;
+    tab[o].modw = (const T*)h.modw;
+    tab[o].etrace = (T*)h.etrace;
+    tab[o].gmod = (T*)h.gmod;
     tab[o].kind = h.kind;
     tab[o].x0 = h.box[0]; tab[o].x1 = h.box[1];
     tab[o].y0 = h.box[2]; tab[o].y1 = h.box[3];
@@ -422,6 +428,9 @@ int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
   if (!p->E || !p->H || !p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
   if (x0 < 0 || x1 > p->nx || x0 > x1) return fail(-1, "bad x range");
   if (x0 == x1) return 0;
+  for (const ObjH& o : p->objs)
+    if (o.kind == FDTDHIP_OBJ_ANISOTROPIC_MODULATED && !o.modw)
+      return fail(-1, "modulated object without weights (fdtdhip_plan_set_object_modifier)");
   if (int rc = sync_obj_table<T>(p)) return rc;
   BulkArgs<T> a;
   a.F = (T*)(phaseE ? p->E : p->H);
@@ -660,6 +669,9 @@ template <typename T>
 int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
   if (!p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
   if (!lamE || !lamH || !work) return fail(-1, "null adjoint array");
+  for (const ObjH& o : p->objs)
+    if (o.kind == FDTDHIP_OBJ_ANISOTROPIC_MODULATED && (!o.modw || !o.etrace || !o.trace))
+      return fail(-1, "the adjoint of a modulated object needs its curl and energy traces");
   if (int rc = sync_obj_table<T>(p)) return rc;
   T* lamF = phaseE ? lamE : lamH;
   const T* mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
@@ -995,7 +1007,7 @@ int fdtdhip_plan_add_periodic(fdtdhip_plan* p, int axis) {
 int fdtdhip_plan_add_object(fdtdhip_plan* p, int kind, const int32_t box[6], const void* inv,
                             const void* absorb) {
   if (!p) return fail(-1, "null plan");
-  if (kind < 0 || kind > 2) return fail(-1, "unknown object kind");
+  if (kind < 0 || kind > FDTDHIP_OBJ_ANISOTROPIC_MODULATED) return fail(-1, "unknown object kind");
   if (!box || !inv) return fail(-1, "null object array");
   if (kind == FDTDHIP_OBJ_ABSORBING && !absorb) return fail(-1, "absorbing object needs its factor");
   const int lim[3] = {p->nx, p->ny, p->nz};
@@ -1176,7 +1188,8 @@ int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
 int fdtdhip_plan_set_object_trace(fdtdhip_plan* p, int id, void* trace, int64_t capacity) {
   if (!p) return fail(-1, "null plan");
   if (id < 0 || id >= (int)p->objs.size()) return fail(-1, "unknown object id");
-  if (p->objs[id].kind != FDTDHIP_OBJ_ANISOTROPIC)
+  if (p->objs[id].kind != FDTDHIP_OBJ_ANISOTROPIC &&
+      p->objs[id].kind != FDTDHIP_OBJ_ANISOTROPIC_MODULATED)
     return fail(-1, "curl traces exist for anisotropic objects only");
   p->objs[id].trace = trace;
   p->objs[id].trace_capacity = trace ? capacity : 0;
@@ -1184,6 +1197,20 @@ int fdtdhip_plan_set_object_trace(fdtdhip_plan* p, int id, void* trace, int64_t 
   p->trace_cursor = -1;
   for (const ObjH& o : p->objs)
     if (o.trace && o.trace_capacity > 0) p->trace_cursor = 0;
+  return 0;
+}
+
+int fdtdhip_plan_set_object_modifier(fdtdhip_plan* p, int id, const void* weights,
+                                     void* energy_trace, void* grad_weights) {
+  if (!p) return fail(-1, "null plan");
+  if (id < 0 || id >= (int)p->objs.size()) return fail(-1, "unknown object id");
+  if (p->objs[id].kind != FDTDHIP_OBJ_ANISOTROPIC_MODULATED)
+    return fail(-1, "not a modulated anisotropic object");
+  if (!weights) return fail(-1, "null modifier weights");
+  p->objs[id].modw = weights;
+  p->objs[id].etrace = energy_trace;
+  p->objs[id].gmod = grad_weights;
+  p->obj_dirty = true;
   return 0;
 }
 

@@ -38,6 +38,10 @@ struct ObjK {
   T* trace;         // differentiable runs: (steps, box, 3) curl of the driving field inside the
                     // box, written by the forward E half step, read by the adjoint; or null
   T* grad;          // adjoint: accumulated gradient of the loss w.r.t. `inv`, same shape; or null
+  // kind 3 (anisotropic, tensor modulated by the local field energies):
+  const T* modw;    // (9, 3): per tensor entry the weights of sum(E^2), sum(H^2) and the bias
+  T* etrace;        // differentiable runs: (steps, box, 2) the two energies per step; or null
+  T* gmod;          // adjoint: (box, 9, 3) per-cell gradient contributions to `modw`; or null
   int kind;
   int x0, x1, y0, y1, z0, z1;
 };

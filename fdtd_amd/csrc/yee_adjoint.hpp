@@ -91,6 +91,33 @@ __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
         g[c] += ((a.sc * O.inv[oc * 3 + c]) / (T(1) + f)) * lam[c];
         lam[c] *= (T(1) - f) / (T(1) + f);
       }
+    } else if (O.kind == 3) {
+      // forward: E_r += sc * sum_c (M_rc * mod_rc) * cu_c with mod from the traced energies,
+      // which are constants of the step (the reference takes them without gradient,
+      // fdtd/objects.py:329-333)
+      if (!O.etrace || !O.trace || a.trace_step < 0) continue;  // refused on the host
+      const int64_t box = (int64_t)(O.x1 - O.x0) * (O.y1 - O.y0) * (O.z1 - O.z0);
+      const T* et = O.etrace + (a.trace_step * box + oc) * 2;
+      const T* cu = O.trace + (a.trace_step * box + oc) * 3;
+      const T eE = et[0], eH = et[1];
+      const T* M = O.inv + oc * 9;
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int dcol = 0; dcol < 3; ++dcol) {
+          const T* w = O.modw + (rr * 3 + dcol) * 3;
+          const T mod = T(1) / (T(1) + exp(-(w[0] * eE + w[1] * eH + w[2])));
+          g[dcol] += a.sc * ((M[rr * 3 + dcol] * mod) * lam[rr]);
+          const T outer = (a.sc * lam[rr]) * cu[dcol];  // dL/d(M_rc * mod_rc)
+          if (O.grad) O.grad[oc * 9 + rr * 3 + dcol] += outer * mod;
+          if (O.gmod) {
+            const T dz = (outer * M[rr * 3 + dcol]) * (mod * (T(1) - mod));
+            T* gm = O.gmod + (oc * 9 + rr * 3 + dcol) * 3;
+            gm[0] += dz * eE;
+            gm[1] += dz * eH;
+            gm[2] += dz;
+          }
+        }
     } else {
       const T* M = O.inv + oc * 9;
 #pragma unroll

@@ -97,7 +97,7 @@ __device__ __forceinline__ bool in_hull(const BulkArgs<T>& a, int i, int j, int 
 template <typename T, bool HAS_PML, bool HAS_OBJ>
 __device__ __forceinline__ void finish_E(const BulkArgs<T>& a, int i, int j, int k,
                                          const Diffs<T>& d, T e[3], const T m[3],
-                                         bool store = true) {
+                                         const T hs[3], bool store = true) {
   T cu[3];
   cu[0] = d.y_z - d.z_y;
   cu[1] = d.z_x - d.x_z;
@@ -121,6 +121,38 @@ __device__ __forceinline__ void finish_E(const BulkArgs<T>& a, int i, int j, int
           e[c] *= (T(1) - f) / (T(1) + f);
           e[c] += ((a.sc * O.inv[oc * 3 + c]) * cu[c]) / (T(1) + f);
         }
+      } else if (O.kind == 3) {
+        // tensor entries scaled by sigmoid(w_E*sum(E^2) + w_H*sum(H^2) + bias), the
+        // energies taken from the fields as they are at this point of the half step
+        // (reference fdtd/objects.py:328-349)
+        const T eE = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+        const T eH = hs[0] * hs[0] + hs[1] * hs[1] + hs[2] * hs[2];
+        if (store && a.trace_step >= 0) {
+          const int64_t box = (int64_t)(O.x1 - O.x0) * (O.y1 - O.y0) * (O.z1 - O.z0);
+          if (O.trace) {
+            T* tr = O.trace + (a.trace_step * box + oc) * 3;
+            tr[0] = cu[0]; tr[1] = cu[1]; tr[2] = cu[2];
+          }
+          if (O.etrace) {
+            T* et = O.etrace + (a.trace_step * box + oc) * 2;
+            et[0] = eE; et[1] = eH;
+          }
+        }
+        T add[3];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          const T* M = O.inv + oc * 9 + rr * 3;
+          T s = T(0);
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            const T* w = O.modw + (rr * 3 + cc) * 3;
+            const T mod = T(1) / (T(1) + exp(-(w[0] * eE + w[1] * eH + w[2])));
+            s += (M[cc] * mod) * cu[cc];
+          }
+          add[rr] = a.sc * s;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) e[rr] += add[rr];
       } else {
         if (store && O.trace && a.trace_step >= 0) {  // differentiable run: keep the curl
           const int64_t box =
@@ -253,7 +285,8 @@ __global__ __launch_bounds__(256) void bulk_E_generic(BulkArgs<T> a) {
   T e[3] = {a.F[c3], a.F[c3 + 1], a.F[c3 + 2]};
   T m[3];
   cell_material<T, false, HAS_OBJ>(a, c3, i, j, k, m);
-  finish_E<T, HAS_PML, HAS_OBJ>(a, i, j, k, d, e, m);
+  const T hs[3] = {hx, hy, hz};
+  finish_E<T, HAS_PML, HAS_OBJ>(a, i, j, k, d, e, m, hs);
   a.F[c3] = e[0];
   a.F[c3 + 1] = e[1];
   a.F[c3 + 2] = e[2];

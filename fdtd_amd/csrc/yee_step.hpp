@@ -78,7 +78,7 @@ __device__ __forceinline__ void new_E(const StepArgs<T>& a, int i, int j, int k,
   T m[3];
   load3<T, false>(a.e.F + c3, e[0], e[1], e[2]);
   load3<T, false>(a.e.mat + c3, m[0], m[1], m[2]);
-  finish_E<T, HAS_PML, HAS_OBJ>(a.e, i, j, k, d, e, m, OWNER);
+  finish_E<T, HAS_PML, HAS_OBJ>(a.e, i, j, k, d, e, m, hc, OWNER);
   add_sources<T>(a, c3, e);
 }
 

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void bulk_E_rows(BulkArgs<T> a) {
   d.y_z = hasy ? hz - yz : T(0);
   d.z_x = hasz ? hx - zx : T(0);
   d.z_y = hasz ? hy - zy : T(0);
-  finish_E<T, HAS_PML, HAS_OBJ>(a, i, j, k, d, e, m);
+  const T hs[3] = {hx, hy, hz};
+  finish_E<T, HAS_PML, HAS_OBJ>(a, i, j, k, d, e, m, hs);
   store3<T, NTS>(a.F + c3, e[0], e[1], e[2]);
 }
 

@@ -176,20 +176,58 @@ class AnisotropicObject(Object):
 
 
 class LearnableAnisotropicObject(AnisotropicObject):
-    """Anisotropic box whose tensor is a leaf that collects gradients
-    (reference fdtd/objects.py:276-349 with ``is_substrate=False``)."""
+    """Anisotropic box whose tensor is a leaf that collects gradients (reference
+    fdtd/objects.py:276-349).
+
+    ``is_substrate=True`` scales the tensor, every E half step, by
+    ``sigmoid(nonlin_conv(energies))``: a 1x1 convolution (``self.nonlin_conv``, a
+    ``torch.nn.Conv2d(2, 9, 1)`` whose weight and bias are learnable too) from the
+    cell's ``sum(E**2)`` and ``sum(H**2)`` to the nine tensor entries (reference
+    fdtd/objects.py:328-337).  The native kernels evaluate it per cell, so the box may
+    have any extent along z (the reference's reshape only works for ``Nz == 1``)."""
 
     def __init__(self, permittivity: Tensorlike, is_substrate=False, name: str = None, device=None):
         super().__init__(permittivity, name)
-        if is_substrate:
-            raise NotImplementedError(
-                "the energy-dependent substrate modifier (is_substrate=True) is not part of "
-                "the hip backend"
-            )
-        self.is_substrate = False
+        self.is_substrate = bool(is_substrate)
         self.device = device
+        if not bd.staging:
+            self.nonlin_conv = torch.nn.Conv2d(2, 9, kernel_size=1, stride=1, device=bd.device,
+                                               dtype=bd.float)
+        else:
+            self.nonlin_conv = torch.nn.Conv2d(2, 9, kernel_size=1, stride=1, dtype=bd.float)
+        if self.is_substrate:
+            self._native_kind = _lib.OBJ_ANISOTROPIC_MODULATED
+        self._weights_key = None
+        self._weights = None
+        self._mod_buffers = (None, None)  # (energy trace, weight-gradient buffer) of a recorded run
 
     def _register_grid(self, grid: Grid, x: slice = None, y: slice = None, z: slice = None):
         super()._register_grid(grid=grid, x=x, y=y, z=z)
         self.inverse_permittivity.requires_grad = True
         self.inverse_permittivity.retain_grad()
+
+    # -- the modifier's weights as the kernels take them: (9, 3) = [w_E, w_H, bias] per entry
+    def _packed_weights(self):
+        w, b = self.nonlin_conv.weight, self.nonlin_conv.bias
+        key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+        if key != self._weights_key:
+            self._weights = torch.cat(
+                [w.detach().reshape(9, 2), b.detach().reshape(9, 1)], dim=1
+            ).to(device=bd.device, dtype=bd.float).contiguous()
+            self._weights_key = key
+        return self._weights
+
+    def _native_add(self, lib, plan):
+        super()._native_add(lib, plan)
+        self._weights_key = None
+        self._native_refresh(lib, plan)
+
+    def _native_refresh(self, lib, plan):
+        """Hand the current modifier weights (and, during a recorded run or its backward
+        pass, the trace and gradient buffers) to the plan; called before every run."""
+        if not self.is_substrate or self.Nx == 0:
+            return
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        trace, grad = self._mod_buffers
+        _lib.check(lib.fdtdhip_plan_set_object_modifier(
+            plan, self._native_id, ptr(self._packed_weights()), ptr(trace), ptr(grad)))

@@ -42,6 +42,7 @@ extern "C" {
 #define FDTDHIP_OBJ_ISOTROPIC 0
 #define FDTDHIP_OBJ_ABSORBING 1
 #define FDTDHIP_OBJ_ANISOTROPIC 2
+#define FDTDHIP_OBJ_ANISOTROPIC_MODULATED 3
 
 /* source kinds (reference fdtd/sources.py: PointSource 26 / LineSource 170 add to
  * one component at a list of cells; PlaneSource 359 overwrites a box) */
@@ -202,6 +203,21 @@ int fdtdhip_run(fdtdhip_plan* plan, int64_t q0, int64_t nsteps);
  *   `work` is a scratch array of cells*6 elements.  Single-device grids only. */
 int fdtdhip_plan_set_object_trace(fdtdhip_plan* plan, int id, void* trace, int64_t capacity);
 int fdtdhip_plan_set_object_grad(fdtdhip_plan* plan, int id, void* grad);
+
+/* FDTDHIP_OBJ_ANISOTROPIC_MODULATED: an anisotropic object (inv: (bx,by,bz,3,3)) whose
+ * tensor entries are scaled, every E half step, by
+ *     sigmoid(w[n][0]*sum(E^2) + w[n][1]*sum(H^2) + w[n][2]),   n = 3*row + column,
+ * with the energies of the cell's own fields as they are when the object acts
+ * (reference fdtd/objects.py:328-349, LearnableAnisotropicObject(is_substrate=True):
+ * a 1x1 convolution from the two energies to nine channels, then a sigmoid).
+ * `weights`: device (9,3), required before the first step and whenever the values
+ * change.  Differentiable runs: `energy_trace` device (capacity, box, 2) filled by the
+ * forward E half steps next to the curl trace (same capacity), read by the adjoint;
+ * `grad_weights` device (box, 9, 3), to which the adjoint adds each cell's contribution to
+ * dL/dweights (the caller sums over cells).  As in the reference no gradient flows
+ * through the energies. */
+int fdtdhip_plan_set_object_modifier(fdtdhip_plan* plan, int id, const void* weights,
+                                     void* energy_trace, void* grad_weights);
 int fdtdhip_plan_set_pml_adjoint(fdtdhip_plan* plan, int id, void* lam_psiE, void* lam_psiH);
 int fdtdhip_adjoint_run(fdtdhip_plan* plan, int64_t nsteps, void* lamE, void* lamH, void* work);
 

@@ -5,8 +5,8 @@
 Runs every scene of ``scenes.ADJOINT_SCENES`` with the reference's ``torch`` (CPU,
 float64) backend, back-propagates the scene's loss with torch autograd exactly as
 reference examples/learnable_focus.py:117-128 does, and stores loss, final fields
-and the gradient of every LearnableAnisotropicObject tensor in
-``<scene>.npz``.  Numbers only.
+and the gradient of every LearnableAnisotropicObject tensor (for a substrate object
+also of its modifier's convolution weights) in ``<scene>.npz``.  Numbers only.
 """
 
 import contextlib
@@ -41,9 +41,12 @@ def main():
         loss.backward()
         out = dict(loss=np.array(loss.item()), E=grid.E.detach().numpy(), H=grid.H.detach().numpy())
         for n, (kind, t, _, _) in enumerate(made):
-            if kind == "learnable":
+            if kind in ("learnable", "substrate"):
                 out[f"grad{n}"] = t.inverse_permittivity.grad.numpy()
                 out[f"inv{n}"] = t.inverse_permittivity.detach().numpy()
+            if kind == "substrate":
+                out[f"gradw{n}"] = t.nonlin_conv.weight.grad.numpy()
+                out[f"gradb{n}"] = t.nonlin_conv.bias.grad.numpy()
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **out)
         g = [np.linalg.norm(v) for k, v in out.items() if k.startswith("grad")]

@@ -275,6 +275,22 @@ ADJOINT_SCENES = {
         steps=24, chunks=(10, 14),     # two consecutive runs chained through the state
         loss=dict(kind="dense", seed=5),
     ),
+    # the research set-up of reference cortical/resonate_img.py:172-187 in small: learnable
+    # frames around a substrate whose tensor is modulated by the local field energies
+    "adjoint_substrate2d": dict(
+        grid=dict(shape=(30, 28, 1)),
+        items=[
+            ("periodic",  (S(None), S(None), 0), {}),
+            ("learnable", (S(0, 4), S(None), S(None)), dict(permittivity=2.5)),
+            ("learnable", (S(None), S(-4, None), S(None)), dict(permittivity=2.5), dict(offdiag_seed=8, offdiag_scale=0.03)),
+            ("substrate", (S(4, 26), S(4, 24), S(None)), dict(permittivity=2.5),
+             dict(offdiag_seed=9, offdiag_scale=0.04, conv_seed=11, conv_scale=150.0)),
+            ("point",     (12, 10, 0), dict(period=9)),
+            ("point",     (20, 17, 0), dict(period=7, amplitude=0.6)),
+        ],
+        steps=40, chunks=(25, 15),
+        loss=dict(kind="dense", seed=6),
+    ),
 }
 
 
@@ -321,16 +337,34 @@ def build_api(scene, fdtd, grid_factory=None):
             "pml": fdtd.PML, "periodic": fdtd.PeriodicBoundary, "object": fdtd.Object,
             "absorbing": fdtd.AbsorbingObject, "anisotropic": fdtd.AnisotropicObject,
             "learnable": fdtd.LearnableAnisotropicObject,
+            "substrate": lambda **k: fdtd.LearnableAnisotropicObject(is_substrate=True, **k),
             "point": fdtd.PointSource, "line": fdtd.LineSource, "plane": fdtd.PlaneSource,
             "linedet": fdtd.LineDetector, "blockdet": fdtd.BlockDetector,
             "currentdet": fdtd.CurrentDetector,
         }[kind]
         thing = cls(**kw)
         grid[key] = thing
-        if kind in ("anisotropic", "learnable") and extra:
+        if kind in ("anisotropic", "learnable", "substrate") and "offdiag_seed" in extra:
             fill_offdiag(thing, extra)
+        if kind == "substrate":
+            set_modifier_weights(thing, extra)
         made.append((kind, thing, kw, extra))
     return grid, made
+
+
+def set_modifier_weights(obj, extra):
+    """Reproducible weights for the 1x1 convolution of a substrate object's energy-dependent
+    modifier (reference fdtd/objects.py:294, 328-337): 9 output channels from the two
+    energies, scaled so that the sigmoid leaves its linear range for the scene's fields."""
+    import torch
+
+    rs = np.random.RandomState(extra["conv_seed"])
+    w = extra["conv_scale"] * rs.randn(9, 2, 1, 1)
+    b = 0.5 * rs.randn(9)
+    conv = obj.nonlin_conv
+    with torch.no_grad():
+        conv.weight.copy_(torch.as_tensor(w, dtype=conv.weight.dtype, device=conv.weight.device))
+        conv.bias.copy_(torch.as_tensor(b, dtype=conv.bias.dtype, device=conv.bias.device))
 
 
 def offdiag_values(shape5, extra):

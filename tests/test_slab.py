@@ -138,16 +138,22 @@ def _adjoint_worker(rank, world, port, scene_name, out):
         torch.cuda.synchronize()
         mine = {"loss": loss.item()}
         for n, (kind, t, _, _) in enumerate(made):
-            if kind == "learnable":
+            if kind in ("learnable", "substrate"):
                 g = t.inverse_permittivity.grad if t.Nx > 0 else None
                 mine[f"grad{n}"] = g.cpu().numpy() if g is not None else None
+            if kind == "substrate":   # every rank holds the whole weights, and a part of their gradient
+                for key, p in ((f"gradw{n}", t.nonlin_conv.weight), (f"gradb{n}", t.nonlin_conv.bias)):
+                    mine[key] = p.grad.cpu().numpy() if p.grad is not None else None
         parts = [None] * world
         dist.all_gather_object(parts, mine)
         if rank == 0:
             res = {"loss": sum(p["loss"] for p in parts)}
             for key in mine:
-                if key.startswith("grad"):
-                    res[key] = np.concatenate([p[key] for p in parts if p[key] is not None], axis=0)
+                have = [p[key] for p in parts if p[key] is not None]
+                if key.startswith("gradw") or key.startswith("gradb"):
+                    res[key] = sum(have)
+                elif key.startswith("grad"):
+                    res[key] = np.concatenate(have, axis=0)
             np.savez(out, **res)
     finally:
         dist.destroy_process_group()
