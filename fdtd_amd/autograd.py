@@ -42,6 +42,12 @@ def _modulated(objs):
     return [o for o in objs if o._native_kind == _lib.OBJ_ANISOTROPIC_MODULATED]
 
 
+def _modulated_sources(grid):
+    """Seeded energy-modulated sources with cells on this rank."""
+    return [s for s in grid.sources
+            if hasattr(s, "_torch_inputs") and s.cc_dirs is not None and s._native_id is not None]
+
+
 def _active_pmls(grid):
     return [b for b in grid.boundaries if hasattr(b, "thickness") and b._active]
 
@@ -51,6 +57,8 @@ def needs_grad(grid):
     if not torch.is_grad_enabled():
         return False
     if grid.E.requires_grad or grid.H.requires_grad or _learnable(grid):
+        return True
+    if any(hasattr(s, "_torch_inputs") and s.cc_dirs is not None for s in grid.sources):
         return True
     return any(p._psiE.requires_grad or p._psiH.requires_grad for p in _active_pmls(grid))
 
@@ -64,13 +72,16 @@ class _Run(torch.autograd.Function):
     def forward(ctx, grid, n, E, H, *rest):
         objs, pmls = _learnable(grid), _active_pmls(grid)
         mods = _modulated(objs)
-        k = len(objs) + 2 * len(mods)   # object tensors, then (weight, bias) per modulated object
+        srcs = _modulated_sources(grid)   # native ids known: the caller prepared the plan
+        # object tensors, (weight, bias) per modulated object, (P, osc, weight, bias) per source
+        k = len(objs) + 2 * len(mods) + 4 * len(srcs)
+        src_in = rest[len(objs) + 2 * len(mods):k]
         # the run works on fresh state tensors; the inputs keep their values for autograd
         grid.E, grid.H = E.detach().clone(), H.detach().clone()
         psis = [t.detach().clone() for t in rest[k:]]
         for n_p, p in enumerate(pmls):
             p._psiE, p._psiH = psis[2 * n_p], psis[2 * n_p + 1]
-        lib = grid._ensure_plan()
+        lib = grid._ensure_plan()          # binds the fresh state tensors
         plan = grid._plan
         traces, etraces = [], []
         for o in objs:
@@ -82,9 +93,19 @@ class _Run(torch.autograd.Function):
             o._mod_buffers = (et, None)
             o._native_refresh(lib, plan)
             etraces.append(et)
+        q0, src_state = grid.time_steps_passed, []
+        for n_s, src in enumerate(srcs):
+            P, osc = src_in[4 * n_s].detach().contiguous(), src_in[4 * n_s + 1].detach().contiguous()
+            box = src._local_box()
+            cells = (box[1] - box[0]) * (box[3] - box[2]) * (box[5] - box[4])
+            state = [P, osc, src._packed_weights(), bd.zeros((n, cells, 2))]
+            src._recording = (*state, None, None, None, q0)
+            src_state.append(state)
         try:
             grid._native_run(lib, n)
         finally:
+            for src in srcs:
+                src._recording = None
             for o in objs:
                 _lib.check(lib.fdtdhip_plan_set_object_trace(plan, o._native_id, None, 0))
             for o in mods:
@@ -92,6 +113,7 @@ class _Run(torch.autograd.Function):
                 o._native_refresh(lib, plan)
         ctx.grid, ctx.n, ctx.k, ctx.traces, ctx.etraces = grid, n, k, traces, etraces
         ctx.mods = mods
+        ctx.srcs, ctx.src_state, ctx.q0 = srcs, src_state, q0
         # weights as they were during this run (an optimiser may change them before backward)
         ctx.mod_weights = [o._packed_weights().clone() for o in mods]
         ctx.objs, ctx.pmls = objs, pmls
@@ -122,6 +144,12 @@ class _Run(torch.autograd.Function):
         for n_p, p in enumerate(pmls):
             _lib.check(lib.fdtdhip_plan_set_pml_adjoint(
                 plan, p._native_id, _ptr(lam_psi[2 * n_p]), _ptr(lam_psi[2 * n_p + 1])))
+        src_grads = []
+        for src, (P, osc, wb, trace) in zip(ctx.srcs, ctx.src_state):
+            gP, gosc, gwb = torch.zeros_like(P), torch.zeros_like(osc), torch.zeros_like(wb)
+            src._recording = (P, osc, wb, trace, gP, gosc, gwb, ctx.q0)
+            src._native_prepare(lib, plan, ctx.q0, n)
+            src_grads.append((gP, gosc, gwb))
         gmods = []
         for o, et, wb in zip(mods, ctx.etraces, ctx.mod_weights):
             gm = bd.zeros((o.Nx * o.Ny * o.Nz, 9, 3))
@@ -137,6 +165,8 @@ class _Run(torch.autograd.Function):
             for o in mods:
                 o._weights_key = None
                 o._native_refresh(lib, plan)
+            for src in ctx.srcs:
+                src._recording = None
             for p in pmls:
                 _lib.check(lib.fdtdhip_plan_set_pml_adjoint(plan, p._native_id, None, None))
         wgrads = []
@@ -145,7 +175,12 @@ class _Run(torch.autograd.Function):
             w, b = o.nonlin_conv.weight, o.nonlin_conv.bias
             wgrads.append(total[:, :2].reshape(w.shape).to(w.dtype))
             wgrads.append(total[:, 2].reshape(b.shape).to(b.dtype))
-        return (None, None, lamE, lamH, *grads, *wgrads, *lam_psi)
+        sgrads = []
+        for src, (gP, gosc, gwb) in zip(ctx.srcs, src_grads):
+            w, b = src.nonlin_conv.weight, src.nonlin_conv.bias
+            sgrads += [gP, gosc, gwb[:, :2].reshape(w.shape).to(w.dtype),
+                       gwb[:, 2].reshape(b.shape).to(b.dtype)]
+        return (None, None, lamE, lamH, *grads, *wgrads, *sgrads, *lam_psi)
 
 
 def differentiable_advance(grid, n):
@@ -156,6 +191,10 @@ def differentiable_advance(grid, n):
     inputs = [o.inverse_permittivity for o in objs]
     for o in _modulated(objs):
         inputs += [o.nonlin_conv.weight, o.nonlin_conv.bias]
+    grid._ensure_plan()  # decides which sources have cells on this rank
+    for src in _modulated_sources(grid):
+        P, osc = src._torch_inputs(grid.time_steps_passed, n)
+        inputs += [P, osc, src.nonlin_conv.weight, src.nonlin_conv.bias]
     for p in pmls:
         inputs += [p._psiE, p._psiH]
     out = _Run.apply(grid, n, grid.E, grid.H, *inputs)

@@ -92,6 +92,11 @@ struct SourceH {
   int serial = 0;
   double period, phase, frequency, hanning_dt, cycle;
   int pulse;
+  // FDTDHIP_SRC_MODULATED_BOX (fdtdhip_plan_set_modulated_source)
+  int channels = 0;
+  const void *modP = nullptr, *osc = nullptr, *modw = nullptr;
+  int64_t osc_rows = 0, q0 = 0;
+  void *etrace = nullptr, *gP = nullptr, *gosc = nullptr, *gwb = nullptr;
 };
 
 struct DetH {
@@ -586,6 +591,20 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
   }
   for (const SourceH& s : p->sources) {
     if (!(parts & POST_SOURCES)) break;
+    if (s.kind == FDTDHIP_SRC_MODULATED_BOX) {
+      if (!phaseE || !s.modP) continue;  // unseeded: no action (reference fdtd/sources.py:583-585)
+      const int64_t row = q - s.q0;
+      if (row < 0 || row >= s.osc_rows) return fail(-1, "modulated source: step outside its oscillator table");
+      const int64_t total =
+          (int64_t)(s.box[1] - s.box[0]) * (s.box[3] - s.box[2]) * (s.box[5] - s.box[4]);
+      if (total <= 0) continue;
+      T* et = s.etrace ? (T*)s.etrace + row * total * 2 : nullptr;
+      hipLaunchKernelGGL((source_modulated<T>), dim3(blocks_for(total)), dim3(256), 0, p->stream,
+                         (T*)p->E, (const T*)p->H, p->ny, p->nz, s.box[0], s.box[1], s.box[2],
+                         s.box[3], s.box[4], s.box[5], s.compE, (const T*)s.modP,
+                         (const T*)s.osc + row * s.channels, (const T*)s.modw, s.channels, et);
+      continue;
+    }
     const double w = waveform(s, q);
     if (s.kind == FDTDHIP_SRC_ADD_POINTS) {
       if (!phaseE || s.n == 0) continue;
@@ -679,6 +698,21 @@ int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
   // that follow the first periodic one, last first
   for (auto it = p->sources.rbegin(); it != p->sources.rend(); ++it) {
     const SourceH& s = *it;
+    if (s.kind == FDTDHIP_SRC_MODULATED_BOX && phaseE && s.modP) {
+      const int64_t row = p->trace_cursor;
+      const int64_t cells =
+          (int64_t)(s.box[1] - s.box[0]) * (s.box[3] - s.box[2]) * (s.box[5] - s.box[4]);
+      if (cells <= 0) continue;
+      if (!s.etrace || !s.gP || !s.gosc || !s.gwb || row < 0 || row >= s.osc_rows)
+        return fail(-1, "the adjoint of a modulated source needs its energy trace and gradient arrays");
+      hipLaunchKernelGGL((adj_source_modulated<T>), dim3(s.channels), dim3(256), 0, p->stream,
+                         (const T*)lamF, p->ny, p->nz, s.box[0], s.box[1], s.box[2], s.box[3],
+                         s.box[4], s.box[5], s.compE, (const T*)s.modP,
+                         (const T*)s.osc + row * s.channels, (const T*)s.modw,
+                         (const T*)s.etrace + row * cells * 2, (T*)s.gP,
+                         (T*)s.gosc + row * s.channels, (T*)s.gwb);
+      continue;
+    }
     if (s.kind != FDTDHIP_SRC_SET_BOX) continue;
     const int64_t total =
         (int64_t)(s.box[1] - s.box[0]) * (s.box[3] - s.box[2]) * (s.box[5] - s.box[4]);
@@ -1071,6 +1105,40 @@ int fdtdhip_plan_add_source(fdtdhip_plan* p, int kind, int compE, int compH, int
     return fail(-1, "unknown source kind");
   }
   p->sources.push_back(s);
+  return 0;
+}
+
+int fdtdhip_plan_add_modulated_source(fdtdhip_plan* p, const int32_t box[6], int comp,
+                                      int channels) {
+  if (!p) return fail(-1, "null plan");
+  if (!box) return fail(-1, "null source array");
+  if (comp < 0 || comp > 2) return fail(-1, "bad component");
+  if (channels < 1) return fail(-1, "a modulated source needs at least one channel");
+  const int lim[3] = {p->nx, p->ny, p->nz};
+  for (int a = 0; a < 3; ++a)
+    if (box[2 * a] < 0 || box[2 * a + 1] > lim[a] || box[2 * a] > box[2 * a + 1])
+      return fail(-1, "source box outside the grid");
+  SourceH s;
+  s.kind = FDTDHIP_SRC_MODULATED_BOX;
+  s.compE = comp; s.compH = comp; s.n = 1;
+  s.period = 1; s.phase = 0; s.pulse = 0; s.frequency = 0; s.hanning_dt = 0; s.cycle = 1;
+  for (int i = 0; i < 6; ++i) s.box[i] = box[i];
+  s.channels = channels;
+  p->sources.push_back(s);
+  return (int)p->sources.size() - 1;
+}
+
+int fdtdhip_plan_set_modulated_source(fdtdhip_plan* p, int id, const void* P, const void* osc,
+                                      int64_t osc_rows, int64_t q0, const void* weights,
+                                      void* energy_trace, void* grad_P, void* grad_osc,
+                                      void* grad_weights) {
+  if (!p) return fail(-1, "null plan");
+  if (id < 0 || id >= (int)p->sources.size() || p->sources[id].kind != FDTDHIP_SRC_MODULATED_BOX)
+    return fail(-1, "not a modulated source");
+  if (P && (!osc || !weights || osc_rows < 1)) return fail(-1, "modulated source: incomplete inputs");
+  SourceH& s = p->sources[id];
+  s.modP = P; s.osc = osc; s.osc_rows = osc_rows; s.q0 = q0; s.modw = weights;
+  s.etrace = energy_trace; s.gP = grad_P; s.gosc = grad_osc; s.gwb = grad_weights;
   return 0;
 }
 

@@ -274,4 +274,58 @@ __global__ void adj_periodic_copy(T* lam, int nx, int ny, int nz, int axis, int 
   lam[d] = 0;
 }
 
+// Adjoint of source_modulated: the source adds to E without reading a differentiable
+// quantity of the fields (the energies carry no gradient, as in the reference), so the
+// field adjoint passes through; what is collected are the gradients of the source's own
+// inputs.  One workgroup per channel c, lanes over the (x, y) columns of the box:
+//   gP[c][column]  += lam * osc[c] * mod          (every step)
+//   gosc[c]         = sum lam * P * mod           (this step's row)
+//   gwb[c][0..2]   += sum dz * {eE, eH, 1},  dz = lam * osc[c] * P * mod * (1 - mod)
+// Sums over cells go through a fixed LDS tree: reproducible.
+template <typename T>
+__global__ __launch_bounds__(256) void adj_source_modulated(
+    const T* lamE, int ny, int nz, int x0, int x1, int y0, int y1, int z0, int z1, int comp,
+    const T* __restrict__ P, const T* __restrict__ osc, const T* __restrict__ wb,
+    const T* __restrict__ etrace, T* gP, T* gosc, T* gwb) {
+  const int c = blockIdx.x;
+  const int bz = z1 - z0, by = y1 - y0;
+  const int64_t cols = (int64_t)(x1 - x0) * by;
+  const T w0 = wb[c * 3], w1 = wb[c * 3 + 1], w2 = wb[c * 3 + 2], oc = osc[c];
+  T acc[4] = {0, 0, 0, 0};  // d osc, d w_E, d w_H, d bias
+  for (int64_t col = threadIdx.x; col < cols; col += blockDim.x) {
+    const int j = y0 + (int)(col % by), i = x0 + (int)(col / by);
+    const T pc = P[c * cols + col];
+    T gp = T(0);
+    for (int lk = 0; lk < bz; ++lk) {
+      const int64_t t = col * bz + lk;
+      const T lam = lamE[(((int64_t)i * ny + j) * nz + z0 + lk) * 3 + comp];
+      const T eE = etrace[t * 2], eH = etrace[t * 2 + 1];
+      const T mod = T(1) / (T(1) + exp(-(w0 * eE + w1 * eH + w2)));
+      gp += lam * mod;
+      acc[0] += (lam * pc) * mod;
+      const T dz = ((lam * oc) * pc) * (mod * (T(1) - mod));
+      acc[1] += dz * eE;
+      acc[2] += dz * eH;
+      acc[3] += dz;
+    }
+    gP[c * cols + col] += gp * oc;
+  }
+  __shared__ T red[4][256];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) red[n][threadIdx.x] = acc[n];
+  __syncthreads();
+  for (int half = 128; half > 0; half >>= 1) {
+    if ((int)threadIdx.x < half)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) red[n][threadIdx.x] += red[n][threadIdx.x + half];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    gosc[c] = red[0][0];
+    gwb[c * 3] += red[1][0];
+    gwb[c * 3 + 1] += red[2][0];
+    gwb[c * 3 + 2] += red[3][0];
+  }
+}
+
 }  // namespace fdtdhip

@@ -411,6 +411,38 @@ __global__ void source_set_box(T* F, int ny, int nz, int x0, int x1, int y0, int
   F[(((int64_t)i * ny + j) * nz + k) * 3 + comp] = value;
 }
 
+// Additive source over a box whose strength depends on the local field energies
+// (reference fdtd/sources.py:581-608, CorticalColumnPlaneSource.update_E):
+//   E_comp(cell) += sum_c osc[c] * P[c][column] * sigmoid(w[c][0]*sum(E^2) + w[c][1]*sum(H^2) + w[c][2])
+// with `column` the (x, y) position inside the box; the caller folds the activation
+// image, the normalised direction kernel's footprint and the amplitude into P and
+// evaluates the oscillators of the step into osc.  With etrace the two energies are kept
+// for the adjoint.
+template <typename T>
+__global__ void source_modulated(T* E, const T* H, int ny, int nz, int x0, int x1, int y0, int y1,
+                                 int z0, int z1, int comp, const T* __restrict__ P,
+                                 const T* __restrict__ osc, const T* __restrict__ wb, int channels,
+                                 T* etrace) {
+  const int bz = z1 - z0, by = y1 - y0;
+  const int64_t cols = (int64_t)(x1 - x0) * by, total = cols * bz;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int64_t col = t / bz;
+  const int k = z0 + (int)(t % bz);
+  const int j = y0 + (int)(col % by);
+  const int i = x0 + (int)(col / by);
+  const int64_t c3 = (((int64_t)i * ny + j) * nz + k) * 3;
+  const T eE = E[c3] * E[c3] + E[c3 + 1] * E[c3 + 1] + E[c3 + 2] * E[c3 + 2];
+  const T eH = H[c3] * H[c3] + H[c3 + 1] * H[c3 + 1] + H[c3 + 2] * H[c3 + 2];
+  if (etrace) { etrace[t * 2] = eE; etrace[t * 2 + 1] = eH; }
+  T sum = T(0);
+  for (int c = 0; c < channels; ++c) {
+    const T mod = T(1) / (T(1) + exp(-(wb[c * 3] * eE + wb[c * 3 + 1] * eH + wb[c * 3 + 2])));
+    sum += (osc[c] * P[c * cols + col]) * mod;
+  }
+  E[c3 + comp] += sum;
+}
+
 // Cell-list detector (reference fdtd/detectors.py:117, 123, 250, 263).
 template <typename T>
 __global__ void detect_cells(const T* F, const int64_t* cell, T* out, int64_t n) {

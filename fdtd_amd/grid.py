@@ -325,6 +325,7 @@ class Grid:
         """One electric half step (reference fdtd/grid.py:275-299)."""
         self._no_half_step_autograd()
         lib = self._ensure_plan()
+        self._prepare_sources(lib, 1)
         for det in self.detectors:
             det._reserve(lib, self._plan, 1, 0)
         _lib.check(lib.fdtdhip_update_E(self._plan, self.time_steps_passed))
@@ -370,11 +371,19 @@ class Grid:
     def _native_run(self, lib, n):
         """``n`` full steps from ``time_steps_passed`` on the prepared plan (the counter is
         advanced by the caller)."""
+        self._prepare_sources(lib, n)
         for det in self.detectors:
             det._reserve(lib, self._plan, n, n)
         _lib.check(lib.fdtdhip_run(self._plan, self.time_steps_passed, n))
         for det in self.detectors:
             det._commit(n, n)
+
+    def _prepare_sources(self, lib, n):
+        """Sources with per-run inputs hand them to the plan (steps time_steps_passed ...)."""
+        for src in self.sources:
+            prepare = getattr(src, "_native_prepare", None)
+            if prepare is not None:
+                prepare(lib, self._plan, self.time_steps_passed, n)
 
     def _native_adjoint(self, lib, n, lamE, lamH, work):
         """Reverse sweep over the last ``n`` steps (see ``fdtd_amd/autograd.py``)."""

@@ -40,9 +40,10 @@ class _NativeEngine:
     def __init__(self, grid):
         self.grid = grid
 
-    def prepare(self):
+    def prepare(self, n=1):
         self.lib = self.grid._ensure_plan()
         self.plan = self.grid._plan
+        self.grid._prepare_sources(self.lib, n)
 
     def reserve_detectors(self, nE, nH):
         for det in self.grid.detectors:
@@ -234,7 +235,7 @@ class SlabGrid(Grid):
 
     def _native_run(self, lib, n):
         eng = self._engine
-        eng.prepare()
+        eng.prepare(n)
         eng.reserve_detectors(n, n)
         for s in range(n):
             q = self.time_steps_passed + s

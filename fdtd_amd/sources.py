@@ -7,9 +7,13 @@ injection is a small device kernel that runs after the boundaries of the same
 half step (reference fdtd/grid.py:293-295, 319-321).
 """
 
+import ctypes
+
 import numpy as np
+import torch
 
 from . import _lib
+from .backend import backend as bd
 from .grid import Grid
 from .typing_ import List, ListOrSlice, Number, Tuple
 
@@ -264,3 +268,103 @@ class PlaneSource:
         loc = ", ".join(f"{n}=[{s.start}, ... , {s.stop}]" for n, s in
                         (("x", self.x), ("y", self.y), ("z", self.z)))
         return "    " + repr(self) + "\n" + f"        @ {loc}\n"
+
+
+class CorticalColumnPlaneSource(PlaneSource):
+    """Additive source over a plane of "cortical columns" (reference
+    fdtd/sources.py:542-608): every column ``c`` has an activation image, a 3x3 direction
+    kernel, an oscillator (frequency, phase) and a field-energy dependent gate
+    ``sigmoid(nonlin_conv(energies))``; each E half step adds
+
+        amp * sum_c sin(2 pi t f_c + phi_c) * footprint_c * activation_c * gate_c
+
+    to ``E[..., 2]`` on the plane (``t`` = physical time).  ``seed`` provides the column
+    data (torch tensors, which may require grad); ``nonlin_conv`` is a
+    ``torch.nn.Conv2d(2, num_ccs, 1)`` whose parameters learn.  An unseeded source does
+    nothing.  The field-independent factors are prepared with torch (so autograd reaches
+    every seed tensor), the energy gate and the injection run in the native kernels."""
+
+    def __init__(self, period: Number = 15, amplitude: float = 1.0, phase_shift: float = 0.0,
+                 name: str = None, polarization: str = "z", num_cortical_columns=16):
+        # the plane source underneath never fires (reference fdtd/sources.py:553)
+        super().__init__(period, 0, phase_shift, name, polarization)
+        self.num_ccs = int(num_cortical_columns)
+        self.cc_dirs = None
+        kw = {} if bd.staging else {"device": bd.device}
+        self.nonlin_conv = torch.nn.Conv2d(2, self.num_ccs, kernel_size=1, stride=1,
+                                           dtype=bd.float, **kw)
+        self._native_id = None
+        self._held = None        # tensors the plan currently points to
+        self._recording = None   # set by the autograd node while it records a run
+
+    def seed(self, cc_activations, cc_dirs, cc_freqs, cc_phases, amp_scaler):
+        """cc_activations (1, num_ccs, H, W) on the source's plane, cc_dirs (1, num_ccs, 3, 3),
+        cc_freqs and cc_phases (num_ccs,), amp_scaler a number or tensor."""
+        self.cc_activations = cc_activations
+        self.cc_dirs = cc_dirs
+        self.cc_freqs = cc_freqs
+        self.cc_phases = cc_phases
+        self.amp_scaler = amp_scaler
+
+    def _signature(self):
+        return ("cortical", id(self), self.x.start, self.x.stop, self.y.start, self.y.stop,
+                self.z.start, self.z.stop, self.num_ccs)
+
+    def _local_box(self):
+        lo, hi = self.grid._clip_x(self.x.start, self.x.stop)
+        return [lo, hi, self.y.start, self.y.stop, 0, self.grid.Nz]
+
+    def _native_add(self, lib, plan):
+        self._native_id = None
+        box = self._local_box()
+        if box[1] <= box[0]:
+            return
+        # the reference always adds to the last component (fdtd/sources.py:608)
+        self._native_id = _lib.check(lib.fdtdhip_plan_add_modulated_source(
+            plan, _lib.int32s(box), 2, self.num_ccs))
+
+    # -- field-independent factors, with torch so that gradients reach the seed tensors
+    def _torch_inputs(self, q0, n):
+        """(P, osc): P (num_ccs, local columns) = amp * footprint * activation on this
+        rank's part of the plane; osc (n, num_ccs) oscillator values of steps q0..q0+n-1."""
+        g = self.grid
+        ih, iw = self.x.stop - self.x.start, self.y.stop - self.y.start
+        dirs = self.cc_dirs.to(device=bd.device, dtype=bd.float)
+        unit = dirs / dirs.reshape(1, self.num_ccs, -1).sum(-1)[:, :, None, None]
+        ones = torch.ones((1, ih - 2, iw - 2), device=bd.device, dtype=bd.float)
+        footprint = torch.conv_transpose2d(ones, unit, bias=None, stride=1)   # (num_ccs, ih, iw)
+        acts = self.cc_activations.to(device=bd.device, dtype=bd.float)
+        P = (footprint[None] * acts * self.amp_scaler)[0]
+        lo, hi = g._clip_x(self.x.start, self.x.stop)          # local planes of the box
+        first = lo + g.x_offset - self.x.start
+        P = P[:, first:first + (hi - lo)].reshape(self.num_ccs, -1).contiguous()
+        t = (q0 + torch.arange(n, device=bd.device, dtype=bd.float)) * g.time_step
+        freqs = self.cc_freqs.to(device=bd.device, dtype=bd.float)
+        phases = self.cc_phases.to(device=bd.device, dtype=bd.float)
+        osc = torch.sin(2 * np.pi * t[:, None] * freqs[None, :] + phases[None, :]).contiguous()
+        return P, osc
+
+    def _packed_weights(self):
+        w, b = self.nonlin_conv.weight, self.nonlin_conv.bias
+        return torch.cat([w.detach().reshape(self.num_ccs, 2), b.detach().reshape(self.num_ccs, 1)],
+                         dim=1).to(device=bd.device, dtype=bd.float).contiguous()
+
+    def _native_prepare(self, lib, plan, q0, n):
+        """Give the plan this source's inputs for steps q0..q0+n-1 (called before every run)."""
+        if self._native_id is None:
+            return
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        if self.cc_dirs is None:
+            _lib.check(lib.fdtdhip_plan_set_modulated_source(
+                plan, self._native_id, None, None, 0, 0, None, None, None, None, None))
+            return
+        if self._recording is not None:
+            P, osc, wb, trace, gP, gosc, gwb, q0 = self._recording
+        else:
+            with torch.no_grad():
+                P, osc = self._torch_inputs(q0, n)
+            wb, trace, gP, gosc, gwb = self._packed_weights(), None, None, None, None
+        self._held = (P, osc, wb, trace, gP, gosc, gwb)
+        _lib.check(lib.fdtdhip_plan_set_modulated_source(
+            plan, self._native_id, ptr(P), ptr(osc), osc.shape[0], q0, ptr(wb), ptr(trace),
+            ptr(gP), ptr(gosc), ptr(gwb)))

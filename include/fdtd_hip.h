@@ -48,6 +48,7 @@ extern "C" {
  * one component at a list of cells; PlaneSource 359 overwrites a box) */
 #define FDTDHIP_SRC_ADD_POINTS 0
 #define FDTDHIP_SRC_SET_BOX 1
+#define FDTDHIP_SRC_MODULATED_BOX 2 /* registered with fdtdhip_plan_add_modulated_source */
 
 /* detector kinds (reference fdtd/detectors.py: LineDetector 20 and BlockDetector
  * 146 copy the three components of listed cells; CurrentDetector 284) */
@@ -129,6 +130,30 @@ int fdtdhip_plan_add_source(fdtdhip_plan* plan, int kind, int comp_E, int comp_H
                             int64_t n, const int32_t* cells, const double* profile,
                             double period, double phase, int pulse, double frequency,
                             double hanning_dt, double cycle);
+
+/* Energy-modulated additive source over box = {x0,x1,y0,y1,z0,z1} (reference
+ * fdtd/sources.py:542-608, CorticalColumnPlaneSource): after the boundaries of every E
+ * half step
+ *     E[cell, comp] += sum_c osc[q - q0][c] * P[c][column]
+ *                            * sigmoid(w[c][0]*sum(E^2) + w[c][1]*sum(H^2) + w[c][2])
+ * with the energies of the cell's own fields at that moment and `column` the (x, y)
+ * position in the box, x-major.  The reference's factors that do not depend on the
+ * fields -- activation image, footprint of the normalised 3x3 direction kernels
+ * (conv_transpose2d of ones, sources.py:599-602), amplitude -- are one device array
+ * P (channels, columns); its oscillators sin(2*pi*t*f_c + phi_c) are a device table
+ * osc (osc_rows, channels) for the steps q0 .. q0+osc_rows-1; weights is device
+ * (channels, 3).  Until inputs are set (P = NULL) the source does nothing, as an
+ * unseeded source in the reference.  Returns the source id.
+ * Differentiable runs: energy_trace device (osc_rows, box cells, 2) is filled by the
+ * forward pass; the reverse sweep then needs grad_P (channels, columns; accumulated),
+ * grad_osc (osc_rows, channels; written per step) and grad_weights (channels, 3;
+ * accumulated).  No gradient flows through the energies (sources.py:588-592). */
+int fdtdhip_plan_add_modulated_source(fdtdhip_plan* plan, const int32_t box[6], int comp,
+                                      int channels);
+int fdtdhip_plan_set_modulated_source(fdtdhip_plan* plan, int id, const void* P, const void* osc,
+                                      int64_t osc_rows, int64_t q0, const void* weights,
+                                      void* energy_trace, void* grad_P, void* grad_osc,
+                                      void* grad_weights);
 
 /* Detector over n points.  FDTDHIP_DET_CELLS: cells = HOST 3*n ints; each
  * reading is (n,3) (reference fdtd/detectors.py:114-124, 241-265).

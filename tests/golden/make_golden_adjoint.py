@@ -47,6 +47,9 @@ def main():
             if kind == "substrate":
                 out[f"gradw{n}"] = t.nonlin_conv.weight.grad.numpy()
                 out[f"gradb{n}"] = t.nonlin_conv.bias.grad.numpy()
+            if kind == "cortical":
+                for key, leaf in t.leaves.items():
+                    out[f"src{n}_{key}"] = leaf.grad.numpy()
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **out)
         g = [np.linalg.norm(v) for k, v in out.items() if k.startswith("grad")]

@@ -291,6 +291,22 @@ ADJOINT_SCENES = {
         steps=40, chunks=(25, 15),
         loss=dict(kind="dense", seed=6),
     ),
+    # substrate driven by a cortical-column source (reference cortical/resonate_img.py:177-187),
+    # advanced one step at a time as reference cortical/autoencoder.py:108-109 does, then in a block
+    "adjoint_cortical2d": dict(
+        grid=dict(shape=(26, 24, 1)),
+        items=[
+            ("periodic",  (S(None), S(None), 0), {}),
+            ("learnable", (S(0, 3), S(None), S(None)), dict(permittivity=2.5)),
+            ("cortical",  (S(4, 20), S(5, 19), 0), dict(period=12, polarization="x", num_cortical_columns=4),
+             dict(seed=21, conv_scale=120.0, amp=0.05)),
+            ("substrate", (S(3, 23), S(3, 21), S(None)), dict(permittivity=2.5),
+             dict(offdiag_seed=12, offdiag_scale=0.03, conv_seed=13, conv_scale=100.0)),
+            ("point",     (10, 12, 0), dict(period=9, amplitude=0.3)),
+        ],
+        steps=30, chunks=(1, 1, 1, 12, 15),
+        loss=dict(kind="dense", seed=7),
+    ),
 }
 
 
@@ -339,6 +355,7 @@ def build_api(scene, fdtd, grid_factory=None):
             "learnable": fdtd.LearnableAnisotropicObject,
             "substrate": lambda **k: fdtd.LearnableAnisotropicObject(is_substrate=True, **k),
             "point": fdtd.PointSource, "line": fdtd.LineSource, "plane": fdtd.PlaneSource,
+            "cortical": getattr(fdtd, "CorticalColumnPlaneSource", None),
             "linedet": fdtd.LineDetector, "blockdet": fdtd.BlockDetector,
             "currentdet": fdtd.CurrentDetector,
         }[kind]
@@ -348,6 +365,8 @@ def build_api(scene, fdtd, grid_factory=None):
             fill_offdiag(thing, extra)
         if kind == "substrate":
             set_modifier_weights(thing, extra)
+        if kind == "cortical":
+            seed_cortical(thing, extra)
         made.append((kind, thing, kw, extra))
     return grid, made
 
@@ -365,6 +384,35 @@ def set_modifier_weights(obj, extra):
     with torch.no_grad():
         conv.weight.copy_(torch.as_tensor(w, dtype=conv.weight.dtype, device=conv.weight.device))
         conv.bias.copy_(torch.as_tensor(b, dtype=conv.bias.dtype, device=conv.bias.device))
+
+
+def seed_cortical(src, extra):
+    """Seed a CorticalColumnPlaneSource the way reference cortical/autoencoder.py:67-74,99-102
+    does, with reproducible numbers: per column an activation image, a 3x3 direction
+    kernel, an oscillator frequency and phase; plus the weights of its modifier's 1x1
+    convolution.  The leaves are kept in ``src.leaves`` for the gradient checks."""
+    import torch
+
+    rs = np.random.RandomState(extra["seed"])
+    cc = src.num_ccs
+    ih, iw = src.x.stop - src.x.start, src.y.stop - src.y.start
+    conv = src.nonlin_conv
+    dev, dt = conv.weight.device, conv.weight.dtype
+
+    def leaf(a):
+        return torch.as_tensor(a, dtype=dt, device=dev).requires_grad_(True)
+
+    acts = leaf(rs.randn(1, cc, ih, iw))
+    dirs = leaf(0.2 + 0.8 * rs.rand(1, cc, 3, 3))
+    periods = 8.0 + 6.0 * rs.rand(cc)                       # in time steps
+    freqs = leaf(1.0 / (periods * src.grid.time_step))
+    phases = leaf(rs.rand(cc))
+    with torch.no_grad():
+        conv.weight.copy_(torch.as_tensor(extra["conv_scale"] * rs.randn(cc, 2, 1, 1), dtype=dt, device=dev))
+        conv.bias.copy_(torch.as_tensor(0.5 * rs.randn(cc), dtype=dt, device=dev))
+    src.seed(acts, dirs, freqs, phases, extra.get("amp", 1.0))
+    src.leaves = dict(acts=acts, dirs=dirs, freqs=freqs, phases=phases,
+                      weight=conv.weight, bias=conv.bias)
 
 
 def offdiag_values(shape5, extra):

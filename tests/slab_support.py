@@ -26,7 +26,7 @@ class OracleSlabEngine:
         self.calls = []
 
     # -- build the oracle twin of the slab from the engine's resolved components
-    def prepare(self):
+    def prepare(self, n=1):
         g = self.grid
         sig = g._signature()
         if self.og is not None and sig == self.sig:

@@ -52,6 +52,12 @@ def test_gradients_match_reference_autograd(name, dtype, tol):
                 assert got is not None and tuple(got.shape) == z[key].shape
                 err = rel_l2(got.cpu().numpy(), z[key])
                 assert err <= tol, f"{name}/{dtype}: {key} rel-L2 {err:.3e}"
+        if kind == "cortical":    # every seed tensor of the source and its gate's weights
+            for key, leaf in t.leaves.items():
+                want = z[f"src{n}_{key}"]
+                assert leaf.grad is not None and tuple(leaf.grad.shape) == want.shape, key
+                err = rel_l2(leaf.grad.cpu().numpy(), want)
+                assert err <= tol, f"{name}/{dtype}: source {key} gradient rel-L2 {err:.3e}"
     assert seen >= 1
 
 
@@ -125,3 +131,31 @@ def test_substrate_forward_without_grad():
         torch.cuda.synchronize()
         assert float(a.E.abs().max()) > 0
         assert torch.equal(a.E, b.E) and torch.equal(a.H, b.H)
+
+
+def test_cortical_source_forward_without_grad():
+    """The energy-gated column source outside autograd (inputs prepared per run under
+    no_grad), stepped as the scene prescribes and by half steps: the reference's fields."""
+    fdtd.set_backend("hip.float64")
+    scene = scenes.ADJOINT_SCENES["adjoint_cortical2d"]
+    z = np.load(os.path.join(GOLDEN, "adjoint_cortical2d.npz"))
+    with torch.no_grad():
+        grid, _ = scenes.build_api(scene, fdtd)
+        for n in scene["chunks"]:
+            grid.run(n, progress_bar=False)
+        assert grid.E.grad_fn is None
+        assert rel_l2(grid.E.cpu().numpy(), z["E"]) <= 1e-12
+        assert rel_l2(grid.H.cpu().numpy(), z["H"]) <= 1e-12
+        half, _ = scenes.build_api(scene, fdtd)
+        for _ in range(scene["steps"]):
+            half.update_E()
+            half.update_H()
+            half.time_steps_passed += 1
+        assert rel_l2(half.E.cpu().numpy(), z["E"]) <= 1e-12
+        # an unseeded source does nothing (reference fdtd/sources.py:583-585)
+        idle, made = scenes.build_api(scene, fdtd)
+        for kind, t, _, _ in made:
+            if kind == "cortical":
+                t.cc_dirs = None
+        idle.run(3, progress_bar=False)
+        assert torch.isfinite(idle.E).all()

@@ -144,13 +144,16 @@ def _adjoint_worker(rank, world, port, scene_name, out):
             if kind == "substrate":   # every rank holds the whole weights, and a part of their gradient
                 for key, p in ((f"gradw{n}", t.nonlin_conv.weight), (f"gradb{n}", t.nonlin_conv.bias)):
                     mine[key] = p.grad.cpu().numpy() if p.grad is not None else None
+            if kind == "cortical":    # seed tensors are whole on every rank, their gradients partial
+                for key, leaf in t.leaves.items():
+                    mine[f"src{n}_{key}"] = leaf.grad.cpu().numpy() if leaf.grad is not None else None
         parts = [None] * world
         dist.all_gather_object(parts, mine)
         if rank == 0:
             res = {"loss": sum(p["loss"] for p in parts)}
             for key in mine:
                 have = [p[key] for p in parts if p[key] is not None]
-                if key.startswith("gradw") or key.startswith("gradb"):
+                if key.startswith("gradw") or key.startswith("gradb") or key.startswith("src"):
                     res[key] = sum(have)
                 elif key.startswith("grad"):
                     res[key] = np.concatenate(have, axis=0)
@@ -172,7 +175,7 @@ def test_slab_gradients_match_reference_autograd(scene_name, tmp_path):
     assert abs(float(got["loss"]) - float(want["loss"])) <= 1e-11 * abs(float(want["loss"]))
     seen = 0
     for key in got.files:
-        if key.startswith("grad"):
+        if key.startswith("grad") or key.startswith("src"):
             assert got[key].shape == want[key].shape
             err = np.linalg.norm((got[key] - want[key]).ravel()) / np.linalg.norm(want[key].ravel())
             assert err <= 1e-10, f"{scene_name}: {key} rel-L2 {err:.3e}"
