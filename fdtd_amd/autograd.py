@@ -186,6 +186,9 @@ class _Run(torch.autograd.Function):
 def differentiable_advance(grid, n):
     """``n`` full steps recorded as one autograd node; re-binds the grid's state tensors
     to the node's outputs."""
+    for src in grid.sources:
+        if getattr(src, "_no_autograd", None):
+            raise NotImplementedError(f"differentiable runs do not cover {src._no_autograd}")
     objs, pmls = _learnable(grid), _active_pmls(grid)
     grid._fields()
     inputs = [o.inverse_permittivity for o in objs]

@@ -97,6 +97,14 @@ struct SourceH {
   const void *modP = nullptr, *osc = nullptr, *modw = nullptr;
   int64_t osc_rows = 0, q0 = 0;
   void *etrace = nullptr, *gP = nullptr, *gosc = nullptr, *gwb = nullptr;
+  // FDTDHIP_SRC_SOFT_POINT (fdtdhip_plan_add_soft_source)
+  double* wave = nullptr;      // device copy of the voltage waveform
+  int64_t nwave = 0, elem0 = 0;
+  double impedance = 0, spacing = 1;
+  int det = -1;                // its loop-current detector (fdtdhip_plan_link_soft_source)
+  const void* prev_current = nullptr;  // last reading taken before this run, or null
+  char *vin = nullptr, *vout = nullptr;
+  int64_t vcap = 0, vused = 0;
 };
 
 struct DetH {
@@ -589,8 +597,23 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
                          mat, k, p->nx, p->ny, p->nz, (T)p->sc, phaseE ? T(1) : T(-1));
     }
   }
-  for (const SourceH& s : p->sources) {
+  for (SourceH& s : p->sources) {
     if (!(parts & POST_SOURCES)) break;
+    if (s.kind == FDTDHIP_SRC_SOFT_POINT) {
+      if (!phaseE || s.nwave < 0) continue;
+      if (s.det < 0 || s.det >= (int)p->dets.size() || p->dets[s.det].kind != FDTDHIP_DET_CURRENT)
+        return fail(-1, "soft source without its current detector (fdtdhip_plan_link_soft_source)");
+      const DetH& d = p->dets[s.det];
+      // the newest reading: in the detector's current output buffer, else the one the caller named
+      const T* cur = (const T*)s.prev_current;
+      if (d.usedH > 0 && d.outH && d.n > 0) cur = (const T*)d.outH + (d.usedH - 1) * d.n;
+      if (s.vin && s.vused >= s.vcap) return fail(-3, "soft source output capacity exhausted");
+      hipLaunchKernelGGL((source_soft_point<T>), dim3(1), dim3(1), 0, p->stream, F, s.elem0, s.wave,
+                         s.nwave, q, s.impedance, s.spacing, cur,
+                         s.vin ? (T*)s.vin + s.vused : nullptr, s.vout ? (T*)s.vout + s.vused : nullptr);
+      if (s.vin) ++s.vused;
+      continue;
+    }
     if (s.kind == FDTDHIP_SRC_MODULATED_BOX) {
       if (!phaseE || !s.modP) continue;  // unseeded: no action (reference fdtd/sources.py:583-585)
       const int64_t row = q - s.q0;
@@ -698,6 +721,8 @@ int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
   // that follow the first periodic one, last first
   for (auto it = p->sources.rbegin(); it != p->sources.rend(); ++it) {
     const SourceH& s = *it;
+    if (s.kind == FDTDHIP_SRC_SOFT_POINT)
+      return fail(-1, "the adjoint does not cover a source fed back from a current detector");
     if (s.kind == FDTDHIP_SRC_MODULATED_BOX && phaseE && s.modP) {
       const int64_t row = p->trace_cursor;
       const int64_t cells =
@@ -1105,6 +1130,54 @@ int fdtdhip_plan_add_source(fdtdhip_plan* p, int kind, int compE, int compH, int
     return fail(-1, "unknown source kind");
   }
   p->sources.push_back(s);
+  return 0;
+}
+
+int fdtdhip_plan_add_soft_source(fdtdhip_plan* p, const int32_t cell[3], const double* waveform,
+                                 int64_t nwave, double impedance, double spacing) {
+  if (!p) return fail(-1, "null plan");
+  if (!cell || nwave < 0 || (nwave > 0 && !waveform)) return fail(-1, "null source array");
+  if (spacing <= 0) return fail(-1, "bad spacing");
+  const int lim[3] = {p->nx, p->ny, p->nz};
+  for (int a = 0; a < 3; ++a)
+    if (cell[a] < 0 || cell[a] >= lim[a]) return fail(-1, "source cell outside the grid");
+  DeviceGuard g(p->device);
+  SourceH s;
+  s.kind = FDTDHIP_SRC_SOFT_POINT;
+  s.compE = s.compH = 2; s.n = 1;
+  s.period = 1; s.phase = 0; s.pulse = 0; s.frequency = 0; s.hanning_dt = 0; s.cycle = 1;
+  for (int i = 0; i < 6; ++i) s.box[i] = 0;
+  s.elem0 = ((((int64_t)cell[0] * p->ny) + cell[1]) * p->nz + cell[2]) * 3 + 2;  // Ez
+  s.nwave = nwave; s.impedance = impedance; s.spacing = spacing;
+  if (nwave > 0) {
+    HIPCHK(hipMalloc((void**)&s.wave, sizeof(double) * (size_t)nwave));
+    p->owned.push_back(s.wave);
+    HIPCHK(hipMemcpy(s.wave, waveform, sizeof(double) * (size_t)nwave, hipMemcpyHostToDevice));
+  }
+  p->sources.push_back(s);
+  return (int)p->sources.size() - 1;
+}
+
+int fdtdhip_plan_link_soft_source(fdtdhip_plan* p, int id, int detector_id) {
+  if (!p) return fail(-1, "null plan");
+  if (id < 0 || id >= (int)p->sources.size() || p->sources[id].kind != FDTDHIP_SRC_SOFT_POINT)
+    return fail(-1, "not a soft source");
+  if (detector_id < 0 || detector_id >= (int)p->dets.size() ||
+      p->dets[detector_id].kind != FDTDHIP_DET_CURRENT)
+    return fail(-1, "not a current detector");
+  p->sources[id].det = detector_id;
+  return 0;
+}
+
+int fdtdhip_plan_set_soft_source_io(fdtdhip_plan* p, int id, const void* prev_current,
+                                    void* vin_out, void* vout_out, int64_t capacity) {
+  if (!p) return fail(-1, "null plan");
+  if (id < 0 || id >= (int)p->sources.size() || p->sources[id].kind != FDTDHIP_SRC_SOFT_POINT)
+    return fail(-1, "not a soft source");
+  SourceH& s = p->sources[id];
+  s.prev_current = prev_current;
+  s.vin = (char*)vin_out; s.vout = (char*)vout_out;
+  s.vcap = capacity; s.vused = 0;
   return 0;
 }
 

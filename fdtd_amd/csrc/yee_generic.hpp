@@ -443,6 +443,23 @@ __global__ void source_modulated(T* E, const T* H, int ny, int nz, int x0, int x
   E[c3 + comp] += sum;
 }
 
+// Voltage source with a series resistance (reference fdtd/sources.py:708-737): one lane.
+//   v_in = waveform[q] (0 past its end); v_out = v_in + Z * I_prev when Z > 0, I_prev the
+//   loop current read after the previous step (0 at q = 0); E[elem] += v_out / spacing.
+// Both voltages are recorded.
+template <typename T>
+__global__ void source_soft_point(T* E, int64_t elem, const double* wave, int64_t nwave,
+                                  int64_t q, double impedance, double spacing, const T* cur,
+                                  T* vin_out, T* vout_out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const double vin = q < nwave ? wave[q] : 0.0;
+  const double current = (q > 0 && cur) ? (double)cur[0] : 0.0;
+  const double vout = impedance > 0 ? vin + impedance * current : vin;
+  E[elem] += (T)(vout / spacing);
+  if (vin_out) vin_out[0] = (T)vin;
+  if (vout_out) vout_out[0] = (T)vout;
+}
+
 // Cell-list detector (reference fdtd/detectors.py:117, 123, 250, 263).
 template <typename T>
 __global__ void detect_cells(const T* F, const int64_t* cell, T* out, int64_t n) {

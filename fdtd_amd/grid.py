@@ -264,6 +264,10 @@ class Grid:
             for group in (self.boundaries, self.objects, self.sources, self.detectors):
                 for thing in group:
                     thing._native_add(lib, self._plan)
+            for src in self.sources:   # links between components, once all have their ids
+                link = getattr(src, "_native_link", None)
+                if link is not None:
+                    link(lib, self._plan)
             self._plan_signature = sig
             self._materials_key = None
         _lib.check(lib.fdtdhip_plan_set_stream(self._plan, _stream_ptr(bd.device)))
@@ -331,6 +335,7 @@ class Grid:
         _lib.check(lib.fdtdhip_update_E(self._plan, self.time_steps_passed))
         for det in self.detectors:
             det._commit(1, 0)
+        self._finish_sources(1)
 
     def update_H(self):
         """One magnetic half step (reference fdtd/grid.py:301-325)."""
@@ -377,6 +382,7 @@ class Grid:
         _lib.check(lib.fdtdhip_run(self._plan, self.time_steps_passed, n))
         for det in self.detectors:
             det._commit(n, n)
+        self._finish_sources(n)
 
     def _prepare_sources(self, lib, n):
         """Sources with per-run inputs hand them to the plan (steps time_steps_passed ...)."""
@@ -384,6 +390,13 @@ class Grid:
             prepare = getattr(src, "_native_prepare", None)
             if prepare is not None:
                 prepare(lib, self._plan, self.time_steps_passed, n)
+
+    def _finish_sources(self, n):
+        """Sources that record per-step values publish the ``n`` new ones."""
+        for src in self.sources:
+            finish = getattr(src, "_native_finish", None)
+            if finish is not None:
+                finish(n)
 
     def _native_adjoint(self, lib, n, lamE, lamH, work):
         """Reverse sweep over the last ``n`` steps (see ``fdtd_amd/autograd.py``)."""

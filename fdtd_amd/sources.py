@@ -368,3 +368,87 @@ class CorticalColumnPlaneSource(PlaneSource):
         _lib.check(lib.fdtdhip_plan_set_modulated_source(
             plan, self._native_id, ptr(P), ptr(osc), osc.shape[0], q0, ptr(wb), ptr(trace),
             ptr(gP), ptr(gosc), ptr(gwb)))
+
+
+class SoftArbitraryPointSource:
+    """Voltage source with a series resistance at one cell (reference
+    fdtd/sources.py:612-740): every step adds ``(waveform_array[q] + impedance * I) /
+    grid_spacing`` to Ez, ``I`` being the reading its own ``CurrentDetector`` (registered at
+    the same cell, ``self.current_detector``) took after the previous step.  The feedback
+    runs on the device; ``input_voltage`` and ``source_voltage`` are lists of per-step
+    device scalars of shape (1, 1, 1), like the reference's nested lists."""
+
+    _no_autograd = "a source fed back from its current detector"
+
+    def __init__(self, waveform_array, name: str = None, impedance: float = 0.0):
+        self.grid = None
+        self.name = name
+        self.current_detector = None
+        self.waveform_array = waveform_array
+        self.impedance = impedance
+        self.input_voltage = []
+        self.source_voltage = []
+        self._native_id = None
+        self._vin = self._vout = None
+
+    def _register_grid(self, grid: Grid, x: Number, y: Number, z: Number):
+        from .detectors import CurrentDetector, _Readings
+
+        if grid.Nx != grid.Nx_global:
+            raise NotImplementedError(
+                "SoftArbitraryPointSource is not available on an x-slab decomposed grid")
+        self.grid = grid
+        grid.sources.append(self)
+        grid._claim_name(self)
+        try:
+            (x,), (y,), (z,) = x, y, z
+        except (TypeError, ValueError):
+            raise ValueError("a point source should be placed on a single grid cell.")
+        self.x, self.y, self.z = grid._handle_tuple((x, y, z))
+        # the reference means to call the detector "<name>_I" (fdtd/sources.py:700-703)
+        self.current_detector = CurrentDetector(
+            name=None if self.name is None else self.name + "_I")
+        grid[self.x, self.y, self.z] = self.current_detector
+        self._vin, self._vout = _Readings((1, 1, 1)), _Readings((1, 1, 1))
+
+    def _signature(self):
+        w = np.asarray(bd.numpy(self.waveform_array) if torch.is_tensor(self.waveform_array)
+                       else self.waveform_array, dtype=np.float64)
+        return ("soft", id(self), self.x, self.y, self.z, float(self.impedance), w.tobytes())
+
+    def _native_add(self, lib, plan):
+        g = self.grid
+        w = np.ascontiguousarray(
+            bd.numpy(self.waveform_array) if torch.is_tensor(self.waveform_array)
+            else self.waveform_array, dtype=np.float64).reshape(-1)
+        cell = [self.x % g.Nx, self.y % g.Ny, self.z % g.Nz]
+        self._native_id = _lib.check(lib.fdtdhip_plan_add_soft_source(
+            plan, _lib.int32s(cell), w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), w.size,
+            float(self.impedance), float(g.grid_spacing)))
+
+    def _native_link(self, lib, plan):
+        """After all components are in the plan: name the detector that feeds this source."""
+        _lib.check(lib.fdtdhip_plan_link_soft_source(plan, self._native_id, self.current_detector._id))
+
+    def _native_prepare(self, lib, plan, q0, n):
+        last = self.current_detector.I[-1] if len(self.current_detector.I) else None
+        pin, pout = self._vin.reserve(n), self._vout.reserve(n)
+        _lib.check(lib.fdtdhip_plan_set_soft_source_io(
+            plan, self._native_id, ctypes.c_void_p(last.data_ptr()) if last is not None else None,
+            ctypes.c_void_p(pin), ctypes.c_void_p(pout), n))
+
+    def _native_finish(self, n):
+        self._vin.commit(n, self.input_voltage)
+        self._vout.commit(n, self.source_voltage)
+
+    def update_E(self):
+        pass
+
+    def update_H(self):
+        pass
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(name={repr(self.name)}, impedance={self.impedance})"
+
+    def __str__(self):
+        return "    " + repr(self) + "\n" + f"        @ x={self.x}, y={self.y}, z={self.z}\n"

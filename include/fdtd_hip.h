@@ -49,6 +49,7 @@ extern "C" {
 #define FDTDHIP_SRC_ADD_POINTS 0
 #define FDTDHIP_SRC_SET_BOX 1
 #define FDTDHIP_SRC_MODULATED_BOX 2 /* registered with fdtdhip_plan_add_modulated_source */
+#define FDTDHIP_SRC_SOFT_POINT 3    /* registered with fdtdhip_plan_add_soft_source */
 
 /* detector kinds (reference fdtd/detectors.py: LineDetector 20 and BlockDetector
  * 146 copy the three components of listed cells; CurrentDetector 284) */
@@ -154,6 +155,25 @@ int fdtdhip_plan_set_modulated_source(fdtdhip_plan* plan, int id, const void* P,
                                       int64_t osc_rows, int64_t q0, const void* weights,
                                       void* energy_trace, void* grad_P, void* grad_osc,
                                       void* grad_weights);
+
+/* Voltage source with a series resistance at one cell (reference fdtd/sources.py:612-737,
+ * SoftArbitraryPointSource): after the boundaries of the E half step of step q
+ *     v_in  = waveform[q]  (0 beyond its nwave samples)
+ *     v_out = v_in + impedance * I   if impedance > 0, else v_in
+ *     E[cell, z] += v_out / spacing
+ * where I is the newest reading of the source's own loop-current detector (0 at q = 0):
+ * the feedback never leaves the device.  waveform: HOST doubles (copied).  Returns the
+ * source id.  fdtdhip_plan_link_soft_source names the FDTDHIP_DET_CURRENT detector (the
+ * reference registers one at the same cell, sources.py:705-706) once it has been added.
+ * fdtdhip_plan_set_soft_source_io, before a run: prev_current = device address of that
+ * detector's last reading taken before this run (first point; NULL: none yet), and two
+ * device arrays of the plan's element type with room for `capacity` steps that receive
+ * v_in and v_out of every step (the reference's input_voltage / source_voltage lists). */
+int fdtdhip_plan_add_soft_source(fdtdhip_plan* plan, const int32_t cell[3], const double* waveform,
+                                 int64_t nwave, double impedance, double spacing);
+int fdtdhip_plan_link_soft_source(fdtdhip_plan* plan, int id, int detector_id);
+int fdtdhip_plan_set_soft_source_io(fdtdhip_plan* plan, int id, const void* prev_current,
+                                    void* vin_out, void* vout_out, int64_t capacity);
 
 /* Detector over n points.  FDTDHIP_DET_CELLS: cells = HOST 3*n ints; each
  * reading is (n,3) (reference fdtd/detectors.py:114-124, 241-265).

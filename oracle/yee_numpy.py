@@ -302,6 +302,36 @@ class OraclePointSource:
         pass
 
 
+class OracleSoftSource:
+    """Voltage source with a series resistance: the voltage of the step plus impedance x
+    the current its own loop detector read after the previous step, divided by the cell
+    size, is added to Ez (reference fdtd/sources.py:708-737; the detector is registered
+    at the same cell, sources.py:705-706)."""
+
+    def __init__(self, grid, cell, waveform, impedance, detector):
+        self.grid, self.cell = grid, tuple(cell)
+        self.waveform_array = np.asarray(waveform)
+        self.impedance = impedance
+        self.current_detector = detector
+        self.input_voltage, self.source_voltage = [], []
+
+    def update_E(self):
+        q = self.grid.time_steps_passed
+        input_voltage = self.waveform_array[q] if q < self.waveform_array.shape[0] else 0.0
+        current = self.current_detector.I[-1][0][0][0] if q > 0 else 0.0
+        if self.impedance > 0:
+            output_voltage = input_voltage + self.impedance * current
+        else:
+            output_voltage = input_voltage
+        x, y, z = self.cell
+        self.grid.E[x, y, z, 2] += output_voltage / self.grid.grid_spacing
+        self.input_voltage.append([[[input_voltage]]])
+        self.source_voltage.append([[[output_voltage]]])
+
+    def update_H(self):
+        pass
+
+
 class OracleLineSource:
     def __init__(self, grid, xs, ys, zs, period=15, amplitude=1.0, phase_shift=0.0,
                  pulse=False, cycle=5, hanning_dt=10.0):
@@ -487,6 +517,12 @@ class OracleGrid:
 
     def add_plane_source(self, box, **kw):
         s = OraclePlaneSource(self, box, **kw)
+        self.sources.append(s)
+        return s
+
+    def add_soft_source(self, cell, waveform, impedance, det_xs, det_ys, det_zs):
+        d = self.add_current_detector(det_xs, det_ys, det_zs)
+        s = OracleSoftSource(self, cell, waveform, impedance, d)
         self.sources.append(s)
         return s
 

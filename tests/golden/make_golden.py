@@ -111,6 +111,19 @@ def one_scene(name, scene):
             r = np.array(rt.I)
             same(np.array(ot.I), r, f"{name}: detector {n} I")
             out[f"det{n}_I"] = r
+        elif kind == "soft":
+            for key, attr in (("vin", "input_voltage"), ("vout", "source_voltage")):
+                r = np.array(getattr(rt, attr), dtype=np.float64)
+                same(np.array(getattr(ot, attr), dtype=np.float64), r, f"{name}: source {n} {attr}")
+                out[f"src{n}_{key}"] = r
+            r = np.array(rt.current_detector.I)
+            same(np.array(ot.current_detector.I), r, f"{name}: source {n} loop current")
+            out[f"src{n}_I"] = r
+            # the reference's own impedance spectrum of this node (fdtd/fourier.py:216-260)
+            from fdtd.fourier import FrequencyRoutines
+            with contextlib.redirect_stdout(io.StringIO()):
+                freqs, spectrum = FrequencyRoutines(rgrid, rt).impedance()
+            out[f"src{n}_imp_freqs"], out[f"src{n}_imp"] = np.asarray(freqs), np.asarray(spectrum)
     path = os.path.join(HERE, f"{name}.npz")
     np.savez_compressed(path, **out)
     print(f"{name}.npz ok  ({os.path.getsize(path) / 1024:.0f} KiB)  sumE2={float((rgrid.E ** 2).sum()):.6e}")
@@ -118,5 +131,7 @@ def one_scene(name, scene):
 
 if __name__ == "__main__":
     curl_kats()
+    only = sys.argv[2:]  # scene names; all scenes when none is given
     for name, scene in scenes.SCENES.items():
-        one_scene(name, scene)
+        if not only or name in only:
+            one_scene(name, scene)

@@ -192,6 +192,29 @@ SCENES = {
 
 
 # scenes for the x-slab decomposition tests (components straddle the slab faces)
+# probe-fed patch in small (reference tests/test_antenna_impedance.py:17-98): lossy plates,
+# a substrate, and a voltage source with a series resistance fed back from its own loop current
+# (0.3: in the reference's field units the loop is unstable above about 0.5).
+SCENES["soft_feed"] = dict(
+    grid=dict(shape=(18, 16, 12), grid_spacing=4e-4),
+    items=[
+        ("pml",       (S(0, 3), S(None), S(None)), {}),
+        ("pml",       (S(-3, None), S(None), S(None)), {}),
+        ("pml",       (S(None), S(0, 3), S(None)), {}),
+        ("pml",       (S(None), S(-3, None), S(None)), {}),
+        ("pml",       (S(None), S(None), S(0, 3)), {}),
+        ("pml",       (S(None), S(None), S(-3, None)), {}),
+        ("absorbing", (S(3, 15), S(3, 13), S(3, 4)), dict(permittivity=1.0, conductivity=1e3)),
+        ("absorbing", (S(5, 13), S(5, 11), S(7, 8)), dict(permittivity=1.0, conductivity=1e3)),
+        ("soft",      (9, 7, 4), dict(waveform_array=("gauss", 40, 14.0, 9.0, 1e-3), impedance=0.3)),
+        ("object",    (S(3, 9), S(3, 13), S(4, 7)), dict(permittivity=2.42)),
+        ("object",    (S(10, 15), S(3, 13), S(4, 7)), dict(permittivity=2.42)),
+        ("soft",      (12, 9, 8), dict(waveform_array=("gauss", 25, 10.0, 6.0, 5e-4), impedance=0.0)),
+        ("linedet",   (S(4, 14), 8, 5), {}),
+    ],
+    steps=60,
+)
+
 SLAB_SCENES = {
     "slab_mix": dict(
         grid=dict(shape=(26, 14, 12)),
@@ -326,6 +349,10 @@ def adjoint_loss(scene, grid, xp):
 def _materialise(v):
     if isinstance(v, tuple) and v and v[0] == "randpos":
         return _randpos(*v[1:])
+    if isinstance(v, tuple) and v and v[0] == "gauss":      # ("gauss", samples, centre, fwhm, peak)
+        _, n, centre, fwhm, peak = v
+        sigma = fwhm / (2.0 * np.sqrt(2.0 * np.log(2.0)))
+        return peak * np.exp(-((np.arange(n) - centre) ** 2) / (2.0 * sigma ** 2))
     return v
 
 
@@ -356,6 +383,9 @@ def build_api(scene, fdtd, grid_factory=None):
             "substrate": lambda **k: fdtd.LearnableAnisotropicObject(is_substrate=True, **k),
             "point": fdtd.PointSource, "line": fdtd.LineSource, "plane": fdtd.PlaneSource,
             "cortical": getattr(fdtd, "CorticalColumnPlaneSource", None),
+            # not exported at the top level by the reference (fdtd/__init__.py:7)
+            "soft": getattr(fdtd, "SoftArbitraryPointSource", None)
+            or getattr(getattr(fdtd, "sources", None), "SoftArbitraryPointSource", None),
             "linedet": fdtd.LineDetector, "blockdet": fdtd.BlockDetector,
             "currentdet": fdtd.CurrentDetector,
         }[kind]
@@ -507,6 +537,12 @@ def resolve(scene, grid, made):
             out["items"].append(d)
         elif kind in ("linedet", "blockdet", "currentdet"):
             out["items"].append(dict(kind=kind, xs=_ints(t.x), ys=_ints(t.y), zs=_ints(t.z)))
+        elif kind == "soft":
+            arrays[f"item{n}_waveform"] = np.asarray(t.waveform_array, dtype=np.float64)
+            d = t.current_detector
+            out["items"].append(dict(kind=kind, cell=_ints([t.x, t.y, t.z]), impedance=float(t.impedance),
+                                     waveform=f"@item{n}_waveform",
+                                     det=[_ints(d.x), _ints(d.y), _ints(d.z)]))
         else:
             raise ValueError(kind)
     return out, arrays
@@ -553,6 +589,8 @@ def build_oracle(resolved, arrays):
             t = grid.add_block_detector(it["xs"], it["ys"], it["zs"])
         elif k == "currentdet":
             t = grid.add_current_detector(it["xs"], it["ys"], it["zs"])
+        elif k == "soft":
+            t = grid.add_soft_source(it["cell"], val(it["waveform"]), it["impedance"], *it["det"])
         else:
             raise ValueError(k)
         made.append((k, t))

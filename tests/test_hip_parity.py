@@ -77,6 +77,11 @@ def test_scene_matches_reference(name, dtype):
         elif kind == "currentdet":
             assert len(t.I) == scene["steps"]
             errs[f"det{n}_I"] = rel_l2(host(t.I), z[f"det{n}_I"])
+        elif kind == "soft":   # both voltage records and the loop current that feeds back
+            assert len(t.input_voltage) == len(t.source_voltage) == scene["steps"]
+            errs[f"src{n}_vin"] = rel_l2(host(t.input_voltage), z[f"src{n}_vin"])
+            errs[f"src{n}_vout"] = rel_l2(host(t.source_voltage), z[f"src{n}_vout"])
+            errs[f"src{n}_I"] = rel_l2(host(t.current_detector.I), z[f"src{n}_I"])
     bad = {k: v for k, v in errs.items() if not v <= tol}
     assert not bad, f"{name}/{dtype}: rel-L2 above {tol}: {bad}"
     if dtype == "float64":
@@ -157,3 +162,30 @@ def test_run_and_half_steps_agree_bitwise(name):
         b.time_steps_passed += 1
     torch.cuda.synchronize()
     assert np.array_equal(host(a.E), host(b.E)) and np.array_equal(host(a.H), host(b.H))
+
+
+def test_impedance_spectrum_matches_reference():
+    """FrequencyRoutines.impedance of the voltage source with series resistance (reference
+    fdtd/fourier.py:216-260, numbers from the reference itself in soft_feed.npz); the
+    transforms run on the device.  Relative L2 <= 1e-9 (FFT summation order differs)."""
+    from fdtd_amd.fourier import FrequencyRoutines
+
+    fdtd.set_backend("hip.float64")
+    scene = scenes.SCENES["soft_feed"]
+    z = np.load(os.path.join(GOLDEN, "soft_feed.npz"))
+    grid, made = scenes.build_api(scene, fdtd)
+    fr0 = FrequencyRoutines(grid, made[8][1])
+    assert fr0.impedance() == ([], [])           # nothing recorded yet
+    scenes.run_scene(scene, grid)
+    for n, (kind, t, _, _) in enumerate(made):
+        if kind == "soft":
+            freqs, spectrum = FrequencyRoutines(grid, t).impedance()
+            assert rel_l2(np.abs(host(freqs)), np.abs(z[f"src{n}_imp_freqs"])) <= 1e-12
+            got, want = host(spectrum), z[f"src{n}_imp"]
+            assert got.shape == want.shape
+            assert np.linalg.norm(got - want) <= 1e-9 * np.linalg.norm(want)
+    det = [t for k, t, _, _ in made if k == "linedet"][0]
+    f, s = FrequencyRoutines(grid, det).FFT()
+    assert f.shape == s.shape and s.shape[0] == 2 * scene["steps"]
+    with pytest.raises(ValueError):
+        FrequencyRoutines(grid, "nonsense").FFT()
