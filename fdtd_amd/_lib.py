@@ -61,6 +61,7 @@ PROTOTYPES = {
     "fdtdhip_adjoint_run": (_i, [_p, _i64, _p, _p, _p]),
     "fdtdhip_adjoint_cells": (_i, [_p, _i, _i64, _p, _p, _p]),
     "fdtdhip_adjoint_gather": (_i, [_p, _i, _p, _p, _p, _p]),
+    "fdtdhip_plane_energy": (_i, [_p, _i, _i, _p, _p]),
     "fdtdhip_plan_enable_timing": (_i, [_p, _i]),
     "fdtdhip_plan_get_timing": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

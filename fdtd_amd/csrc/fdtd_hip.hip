@@ -1401,6 +1401,26 @@ int fdtdhip_adjoint_gather(fdtdhip_plan* p, int phase_E, void* lamE, void* lamH,
                                          (const double*)work_ghost));
 }
 
+int fdtdhip_plane_energy(fdtdhip_plan* p, int axis, int index, void* outE, void* outH) {
+  if (!p) return fail(-1, "null plan");
+  if (!p->E || !p->H) return fail(-1, "fields not set");
+  if (!outE || !outH) return fail(-1, "null output");
+  const int n = axis == 0 ? p->nx : (axis == 1 ? p->ny : p->nz);
+  if (axis < 0 || axis > 2 || index < 0 || index >= n) return fail(-1, "plane outside the grid");
+  DeviceGuard g(p->device);
+  const int64_t cells = p->cells() / n;
+  if (p->dtype == FDTDHIP_F32)
+    hipLaunchKernelGGL((plane_energy<float>), dim3(blocks_for(cells)), dim3(256), 0, p->stream,
+                       (const float*)p->E, (const float*)p->H, p->nx, p->ny, p->nz, axis, index,
+                       (float*)outE, (float*)outH);
+  else
+    hipLaunchKernelGGL((plane_energy<double>), dim3(blocks_for(cells)), dim3(256), 0, p->stream,
+                       (const double*)p->E, (const double*)p->H, p->nx, p->ny, p->nz, axis, index,
+                       (double*)outE, (double*)outH);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int fdtdhip_plan_enable_timing(fdtdhip_plan* p, int on) {
   if (!p) return fail(-1, "null plan");
   DeviceGuard g(p->device);

@@ -492,6 +492,25 @@ __global__ void detect_current(const T* H, const int32_t* xyz, T* out, int64_t n
   out[t] = (cur1 + cur2) / T(2);
 }
 
+// Energy densities sum(E^2), sum(H^2) over the components on one grid plane, in the
+// orientation the reference's plots use (reference fdtd/visualization.py:119-146):
+// axis 0 -> (ny, nz), axis 1 -> (nz, nx) (transposed), axis 2 -> (nx, ny).
+template <typename T>
+__global__ void plane_energy(const T* E, const T* H, int nx, int ny, int nz, int axis, int index,
+                             T* outE, T* outH) {
+  const int rows = axis == 0 ? ny : (axis == 1 ? nz : nx);
+  const int cols = axis == 0 ? nz : (axis == 1 ? nx : ny);
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)rows * cols) return;
+  const int r = (int)(t / cols), c = (int)(t % cols);
+  const int i = axis == 0 ? index : (axis == 1 ? c : r);
+  const int j = axis == 0 ? r : (axis == 1 ? index : c);
+  const int k = axis == 0 ? c : (axis == 1 ? r : index);
+  const int64_t c3 = (((int64_t)i * ny + j) * nz + k) * 3;
+  outE[t] = E[c3] * E[c3] + E[c3 + 1] * E[c3 + 1] + E[c3 + 2] * E[c3 + 2];
+  outH[t] = H[c3] * H[c3] + H[c3 + 1] * H[c3 + 1] + H[c3 + 2] * H[c3 + 2];
+}
+
 // Stand-alone curls (reference fdtd/grid.py:29-76).
 template <typename T, bool FORWARD>
 __global__ void curl_only(const T* G, T* out, int nx, int ny, int nz) {

@@ -316,6 +316,68 @@ class Grid:
         self._materials_key = None
         self._material_scans = 0
 
+    # ------------------------------------------------------------------ output
+    def energy_plane(self, x=None, y=None, z=None):
+        """``(sum(E**2), sum(H**2))`` over the components on one grid plane, as two device
+        tensors oriented like the reference's plots (reference fdtd/visualization.py:85-146:
+        yz plane for ``x``, transposed zx plane for ``y``, xy plane for ``z``); only that
+        plane is read."""
+        given = [(a, v) for a, v in enumerate((x, y, z)) if v is not None]
+        if not given:
+            raise ValueError(
+                "at least one projection plane (x, y or z) should be supplied to visualize the grid!")
+        axis, index = given[0]
+        name = "xyz"[axis]
+        if not isinstance(index, int):
+            raise ValueError(f"the `{name}`-location supplied should be a single integer")
+        if len(given) > 1:
+            raise ValueError(f"if an `{name}`-location is supplied, one should not supply another location!")
+        n = (self.Nx, self.Ny, self.Nz)[axis]
+        if not -n <= index < n:
+            raise IndexError(f"index {index} is out of bounds for axis {axis} with size {n}")
+        lib = self._ensure_plan()
+        rows, cols = [(self.Ny, self.Nz), (self.Nz, self.Nx), (self.Nx, self.Ny)][axis]
+        eE, eH = bd.zeros((rows, cols)), bd.zeros((rows, cols))
+        _lib.check(lib.fdtdhip_plane_energy(self._plan, axis, index % n,
+                                            ctypes.c_void_p(eE.data_ptr()), ctypes.c_void_p(eH.data_ptr())))
+        return eE, eH
+
+    def save_simulation(self, sim_name=None):
+        """Create ``fdtd_output/fdtd_output_<timestamp>[ (<sim_name>)]`` and remember it as
+        the place ``save_data`` writes to (reference fdtd/grid.py:404-436)."""
+        import os
+        from datetime import datetime
+
+        now = datetime.now()
+        full = "-".join(str(v) for v in (now.year, now.month, now.day, now.hour, now.minute, now.second))
+        if sim_name is not None:
+            full = full + " (" + sim_name + ")"
+        self.folder = os.path.abspath(os.path.join("fdtd_output", "fdtd_output_" + full))
+        self.full_sim_name = full
+        os.makedirs(self.folder, exist_ok=True)
+        return self.folder
+
+    def save_data(self):
+        """Write every detector's readings to ``<folder>/detector_readings.npz`` as
+        ``"<name> (E)"`` and ``"<name> (H)"`` (reference fdtd/grid.py:487-502).  Each record
+        is stacked on the device and copied to the host once."""
+        import os
+
+        import numpy as np
+
+        if getattr(self, "folder", None) is None:
+            raise Exception(
+                "Save location not initialized. Please read about 'fdtd.Grid.saveSimulation()' "
+                "or try running 'grid.saveSimulation()'.")
+        dic = {}
+        for detector in self.detectors:
+            values = detector.detector_values()
+            for f in ("E", "H"):
+                rec = values[f]
+                dic[detector.name + f" ({f})"] = (
+                    torch.stack(list(rec)).cpu().numpy() if len(rec) else np.zeros((0,)))
+        np.savez(os.path.join(self.folder, "detector_readings"), **dic)
+
     def __del__(self):
         plan, self._plan = getattr(self, "_plan", None), None
         if plan is not None:

@@ -303,6 +303,13 @@ int fdtdhip_adjoint_gather(fdtdhip_plan* plan, int phase_E, void* lamE, void* la
  * scan into a no-op returning 0. */
 int fdtdhip_plan_scan_materials(fdtdhip_plan* plan, int enable);
 
+/* Energy densities sum(E^2) and sum(H^2) on the grid plane `index` normal to `axis`, the
+ * quantity the reference's plots show (reference fdtd/visualization.py:119-146, which
+ * squares and sums the whole grid to then keep one plane).  outE, outH: device arrays of
+ * (ny,nz) for axis 0, (nz,nx) for axis 1 (the reference transposes that plane), (nx,ny)
+ * for axis 2. */
+int fdtdhip_plane_energy(fdtdhip_plan* plan, int axis, int index, void* outE, void* outH);
+
 /* Kernel timing for benchmarks (the reference only has wall-clock timing around
  * grid.run, examples/old/simulation_benchmark.py:96-107).  While enabled, every
  * bulk kernel launch is bracketed by HIP events on the plan's stream.

@@ -189,3 +189,42 @@ def test_impedance_spectrum_matches_reference():
     assert f.shape == s.shape and s.shape[0] == 2 * scene["steps"]
     with pytest.raises(ValueError):
         FrequencyRoutines(grid, "nonsense").FFT()
+
+
+def test_save_data_and_energy_plane(tmp_path, monkeypatch):
+    """Detector records on disk in the reference's file layout (reference
+    fdtd/grid.py:487-502) and the plane energies of its plots (visualization.py:119-146),
+    against the golden README scene."""
+    fdtd.set_backend("hip.float64")
+    scene = scenes.SCENES["c1_readme"]
+    z = np.load(os.path.join(GOLDEN, "c1_readme.npz"))
+    grid, made = scenes.build_api(scene, fdtd)
+    with pytest.raises(Exception, match="Save location not initialized"):
+        grid.save_data()
+    scenes.run_scene(scene, grid)
+    monkeypatch.chdir(tmp_path)
+    folder = grid.save_simulation("readme")
+    assert os.path.isdir(folder) and folder.endswith("(readme)")
+    grid.save_data()
+    saved = np.load(os.path.join(folder, "detector_readings.npz"))
+    n = [i for i, m in enumerate(made) if m[0] == "linedet"][0]
+    assert sorted(saved.files) == ["detector (E)", "detector (H)"]
+    assert rel_l2(saved["detector (E)"], z[f"det{n}_E"]) <= 1e-12
+    assert rel_l2(saved["detector (H)"], z[f"det{n}_H"]) <= 1e-12
+    eE, eH = grid.energy_plane(z=0)
+    assert rel_l2(host(eE), (z["E"] ** 2).sum(-1)[:, :, 0]) <= 1e-12
+    assert rel_l2(host(eH), (z["H"] ** 2).sum(-1)[:, :, 0]) <= 1e-12
+    with pytest.raises(ValueError):
+        grid.energy_plane()
+    with pytest.raises(ValueError):
+        grid.energy_plane(x=1, y=2)
+    # the other two orientations on a 3-D state
+    g3 = fdtd.Grid((7, 9, 11))
+    rs = np.random.RandomState(2)
+    E, H = rs.randn(7, 9, 11, 3), rs.randn(7, 9, 11, 3)
+    g3.E, g3.H = fdtd.backend.array(E), fdtd.backend.array(H)
+    a, b = g3.energy_plane(x=3)
+    assert rel_l2(host(a), (E ** 2).sum(-1)[3]) <= 1e-14 and rel_l2(host(b), (H ** 2).sum(-1)[3]) <= 1e-14
+    a, b = g3.energy_plane(y=-2)
+    assert rel_l2(host(a), (E ** 2).sum(-1)[:, -2, :].T) <= 1e-14
+    assert rel_l2(host(b), (H ** 2).sum(-1)[:, -2, :].T) <= 1e-14
