@@ -862,8 +862,8 @@ int fused_step(fdtdhip_plan* p, int64_t q) {
     b.nobj = phaseE ? (int)p->objs.size() : 0;
     b.obj = (const ObjK<T>*)p->obj_table;
     b.trace_step = -1;
-    b.mat_const = 0;  // the fused step reads the arrays
     fill_core<T>(p, b);
+    fill_material<T>(p, phaseE, b);
   }
   if (int rc = sync_pml_tables<T>(p)) return rc;
   // p->step_flipped: the state currently lives in the second buffers

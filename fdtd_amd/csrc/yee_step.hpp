@@ -20,7 +20,11 @@
 // steps), so the plan uses it where launch count decides the step time: small
 // grids.  A marching variant that carried planes in registers and exchanged
 // neighbours through LDS cut the loads to 8 per cell but its strided 756-byte row
-// segments cost more DRAM efficiency than the saved traffic returned (2.33 ms).
+// segments cost more DRAM efficiency than the saved traffic returned (2.33 ms); a
+// variant of this kernel that staged the neighbourhood of a 4-row x 64-cell tile in LDS
+// (7 coalesced cell loads per lane) also took 2.33 ms with constant materials, against
+// 1.66 ms for two half steps: four E updates per cell plus the staging arithmetic cost
+// more issue slots than the saved quarter of the traffic is worth.
 //
 // Side effects stay with the owner lane: only it stores the PML memory variables
 // (psi_E to the second psi buffer, because neighbours still read the old one) and
@@ -77,7 +81,7 @@ __device__ __forceinline__ void new_E(const StepArgs<T>& a, int i, int j, int k,
   d.z_y = hasz ? hc[1] - hzm[1] : T(0);
   T m[3];
   load3<T, false>(a.e.F + c3, e[0], e[1], e[2]);
-  load3<T, false>(a.e.mat + c3, m[0], m[1], m[2]);
+  cell_material<T, false, HAS_OBJ>(a.e, c3, i, j, k, m);
   finish_E<T, HAS_PML, HAS_OBJ>(a.e, i, j, k, d, e, m, hc, OWNER);
   add_sources<T>(a, c3, e);
 }
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256) void step_fused(StepArgs<T> a) {
   d.z_x = haszp ? ez[0] - e[0] : T(0);
   d.z_y = haszp ? ez[1] - e[1] : T(0);
   T m[3];
-  load3<T, true>(a.h.mat + c3, m[0], m[1], m[2]);
+  cell_material<T, true, false>(a.h, c3, i, j, k, m);
   finish_H<T, HAS_PML>(a.h, i, j, k, d, hc, m);
   store3<T, true>(a.H1 + c3, hc[0], hc[1], hc[2]);
 }
