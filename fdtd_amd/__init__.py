@@ -11,16 +11,17 @@ __version__ = "0.1.0"
 
 from .backend import backend, set_backend
 from .grid import Grid, curl_E, curl_H
-from .sources import (PointSource, LineSource, PlaneSource, CorticalColumnPlaneSource,
-                      SoftArbitraryPointSource)
+from .sources import (PointSource, CorticalColumnPointSource, LineSource, PlaneSource,
+                      CorticalColumnPlaneSource, SoftArbitraryPointSource)
 from .detectors import LineDetector, BlockDetector, CurrentDetector
 from .objects import Object, AbsorbingObject, AnisotropicObject, LearnableAnisotropicObject
 from .boundaries import PeriodicBoundary, PML, DomainBorderPML
+from .fourier import FrequencyRoutines
 
 __all__ = [
     "backend", "set_backend", "Grid", "curl_E", "curl_H",
-    "PointSource", "LineSource", "PlaneSource", "CorticalColumnPlaneSource", "SoftArbitraryPointSource",
+    "PointSource", "CorticalColumnPointSource", "LineSource", "PlaneSource", "CorticalColumnPlaneSource", "SoftArbitraryPointSource",
     "LineDetector", "BlockDetector", "CurrentDetector",
     "Object", "AbsorbingObject", "AnisotropicObject", "LearnableAnisotropicObject",
-    "PeriodicBoundary", "PML", "DomainBorderPML",
+    "PeriodicBoundary", "PML", "DomainBorderPML", "FrequencyRoutines",
 ]

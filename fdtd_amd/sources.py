@@ -112,6 +112,43 @@ class PointSource(_Waveform):
         return "    " + repr(self) + "\n" + f"        @ x={self.x}, y={self.y}, z={self.z}\n"
 
 
+class CorticalColumnPointSource(PointSource):
+    """Directional point source (reference fdtd/sources.py:133-167): per axis ``a`` it adds
+    ``s * dir_vec[a]`` to Ez of its cell and subtracts the same from the cell one step back
+    along ``a`` (indices wrap like Python's), ``s = sin(2 pi q / period + phase_shift)``.
+    As in the reference every constructor argument except ``dir_vec`` is ignored (its
+    ``super().__init__()`` call passes none on)."""
+
+    def __init__(self, period: Number = 15, amplitude: float = 1.0, phase_shift: float = 0.0,
+                 name: str = None, pulse: bool = False, cycle: int = 5,
+                 hanning_dt: float = 10.0, dir_vec=(1, 1, 1)):
+        super().__init__()
+        self.dir_vec = bd.array([float(v) for v in dir_vec])
+
+    def _signature(self):
+        return super()._signature() + tuple(float(v) for v in self.dir_vec)
+
+    def _native_add(self, lib, plan):
+        g = self.grid
+        d = [float(v) for v in self.dir_vec]
+        # the six additions in the reference's order; the cell itself appears three times,
+        # which the library then injects serially
+        cells = [(self.x - 1, self.y, self.z), (self.x, self.y, self.z),
+                 (self.x, self.y - 1, self.z), (self.x, self.y, self.z),
+                 (self.x, self.y, self.z - 1), (self.x, self.y, self.z)]
+        weights = [-d[0], d[0], -d[1], d[1], -d[2], d[2]]
+        flat, prof = [], []
+        for (x, y, z), w in zip(cells, weights):
+            xl = g._local_x(x % g.Nx_global)
+            if xl is not None:
+                flat += [xl, y % g.Ny, z % g.Nz]
+                prof.append(self.amplitude * w)
+        if prof:
+            _lib.check(lib.fdtdhip_plan_add_source(
+                plan, _lib.SRC_ADD_POINTS, 2, 2, len(prof), _lib.int32s(flat),
+                _lib.doubles(prof), *self._wave_args()))
+
+
 class LineSource(_Waveform):
     """Soft source adding to Ez along a line with a Gaussian profile whose sum is the
     amplitude (reference fdtd/sources.py:170-355)."""

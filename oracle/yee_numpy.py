@@ -302,6 +302,31 @@ class OraclePointSource:
         pass
 
 
+class OracleCCPointSource:
+    """Directional point source (reference fdtd/sources.py:133-167); amplitude 1, period 15,
+    no phase: its constructor forwards none of its arguments."""
+
+    def __init__(self, grid, cell, dir_vec):
+        self.grid, self.cell = grid, tuple(cell)
+        self.dir_vec = np.array(dir_vec, dtype=np.float64)
+        self.amplitude, self.period, self.phase_shift = 1.0, 15, 0.0
+
+    def update_E(self):
+        q = self.grid.time_steps_passed
+        src = self.amplitude * sin(2 * pi * q / self.period + self.phase_shift)
+        x, y, z = self.cell
+        E, d = self.grid.E, self.dir_vec
+        E[x - 1, y, z, 2] -= src * d[0]
+        E[x, y, z, 2] += src * d[0]
+        E[x, y - 1, z, 2] -= src * d[1]
+        E[x, y, z, 2] += src * d[1]
+        E[x, y, z - 1, 2] -= src * d[2]
+        E[x, y, z, 2] += src * d[2]
+
+    def update_H(self):
+        pass
+
+
 class OracleSoftSource:
     """Voltage source with a series resistance: the voltage of the step plus impedance x
     the current its own loop detector read after the previous step, divided by the cell
@@ -517,6 +542,11 @@ class OracleGrid:
 
     def add_plane_source(self, box, **kw):
         s = OraclePlaneSource(self, box, **kw)
+        self.sources.append(s)
+        return s
+
+    def add_cc_point_source(self, cell, dir_vec):
+        s = OracleCCPointSource(self, cell, dir_vec)
         self.sources.append(s)
         return s
 

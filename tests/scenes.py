@@ -215,6 +215,20 @@ SCENES["soft_feed"] = dict(
     steps=60,
 )
 
+# directional point sources, one of them on the low corner so that its backward
+# neighbours wrap around (reference fdtd/sources.py:160-167 with Python's negative indices)
+SCENES["cc_point"] = dict(
+    grid=dict(shape=(13, 12, 11)),
+    items=[
+        ("pml",     (S(None), S(None), S(-3, None)), {}),
+        ("ccpoint", (6, 5, 5), dict(dir_vec=(1.0, -0.5, 0.25))),
+        ("ccpoint", (0, 7, 0), dict(dir_vec=(0.3, 0.0, 2.0), period=9, amplitude=3.0)),   # arguments ignored
+        ("object",  (S(3, 9), S(2, 6), S(3, 8)), dict(permittivity=1.9)),
+        ("linedet", (S(0, 13), 5, 5), {}),
+    ],
+    steps=35,
+)
+
 SLAB_SCENES = {
     "slab_mix": dict(
         grid=dict(shape=(26, 14, 12)),
@@ -383,6 +397,7 @@ def build_api(scene, fdtd, grid_factory=None):
             "substrate": lambda **k: fdtd.LearnableAnisotropicObject(is_substrate=True, **k),
             "point": fdtd.PointSource, "line": fdtd.LineSource, "plane": fdtd.PlaneSource,
             "cortical": getattr(fdtd, "CorticalColumnPlaneSource", None),
+            "ccpoint": getattr(fdtd, "CorticalColumnPointSource", None),
             # not exported at the top level by the reference (fdtd/__init__.py:7)
             "soft": getattr(fdtd, "SoftArbitraryPointSource", None)
             or getattr(getattr(fdtd, "sources", None), "SoftArbitraryPointSource", None),
@@ -537,6 +552,9 @@ def resolve(scene, grid, made):
             out["items"].append(d)
         elif kind in ("linedet", "blockdet", "currentdet"):
             out["items"].append(dict(kind=kind, xs=_ints(t.x), ys=_ints(t.y), zs=_ints(t.z)))
+        elif kind == "ccpoint":
+            out["items"].append(dict(kind=kind, cell=_ints([t.x, t.y, t.z]),
+                                     dir_vec=[float(v) for v in t.dir_vec]))
         elif kind == "soft":
             arrays[f"item{n}_waveform"] = np.asarray(t.waveform_array, dtype=np.float64)
             d = t.current_detector
@@ -589,6 +607,8 @@ def build_oracle(resolved, arrays):
             t = grid.add_block_detector(it["xs"], it["ys"], it["zs"])
         elif k == "currentdet":
             t = grid.add_current_detector(it["xs"], it["ys"], it["zs"])
+        elif k == "ccpoint":
+            t = grid.add_cc_point_source(it["cell"], it["dir_vec"])
         elif k == "soft":
             t = grid.add_soft_source(it["cell"], val(it["waveform"]), it["impedance"], *it["det"])
         else:
