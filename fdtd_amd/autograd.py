@@ -194,7 +194,8 @@ def differentiable_advance(grid, n):
     inputs = [o.inverse_permittivity for o in objs]
     for o in _modulated(objs):
         inputs += [o.nonlin_conv.weight, o.nonlin_conv.bias]
-    grid._ensure_plan()  # decides which sources have cells on this rank
+    if any(hasattr(s, "_torch_inputs") for s in grid.sources):
+        grid._ensure_plan()  # decides which sources have cells on this rank
     for src in _modulated_sources(grid):
         P, osc = src._torch_inputs(grid.time_steps_passed, n)
         inputs += [P, osc, src.nonlin_conv.weight, src.nonlin_conv.bias]
