@@ -704,6 +704,12 @@ int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArg
   a.open_lo = p->H_below ? 1 : 0;
   a.open_hi = p->E_above ? 1 : 0;
   a.wghost = nullptr;
+  const int w = phaseE ? 0 : 1;
+  a.mat_const = p->mat_const[w] ? 1 : 0;
+  for (int c = 0; c < 3; ++c) a.bg[c] = (T)p->mat_bg[w][c];
+  BulkArgs<T> boxes;
+  fill_core<T>(p, boxes);
+  for (int n = 0; n < 6; ++n) { a.hull[n] = boxes.hull[n]; a.core[n] = boxes.core[n]; }
   return 0;
 }
 

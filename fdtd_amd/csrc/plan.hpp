@@ -93,6 +93,10 @@ struct AdjArgs {
   int open_lo, open_hi;
   const T* wghost;     // pass 2: the neighbour's `work` plane across the face the gather
                        // reaches over ((ny,nz,6)), or null
+  int mat_const;       // as in BulkArgs: `mat` is bg outside the object boxes, zero inside
+  T bg[3];
+  int hull[6];         // box containing every object
+  int core[6];         // box no PML slab reaches
 };
 
 }  // namespace fdtdhip

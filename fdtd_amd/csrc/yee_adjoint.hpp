@@ -52,6 +52,42 @@ __device__ __forceinline__ void adj_pml_face(const PmlK<T>& P, int nx, int i, in
   P.psi[slab + s] = P.b[l] * lp1;
 }
 
+// Inverse material of a cell for the adjoint kernels: the proven constant (zero under an
+// object) or the array entry, exactly as the forward kernels took it.
+template <typename T>
+__device__ __forceinline__ void adj_material(const AdjArgs<T>& a, int64_t c3, int i, int j, int k,
+                                             T m[3]) {
+  if (a.mat_const) {
+    bool covered = false;
+    const bool near = i >= a.hull[0] && i < a.hull[1] && j >= a.hull[2] && j < a.hull[3] &&
+                      k >= a.hull[4] && k < a.hull[5];
+    if (a.nobj && __any(near))
+      for (int o = 0; o < a.nobj; ++o) {
+        const ObjK<T> O = a.obj[o];
+        covered |= i >= O.x0 && i < O.x1 && j >= O.y0 && j < O.y1 && k >= O.z0 && k < O.z1;
+      }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) m[c] = covered ? T(0) : a.bg[c];
+  } else {
+    m[0] = a.mat[c3]; m[1] = a.mat[c3 + 1]; m[2] = a.mat[c3 + 2];
+  }
+}
+
+// Wave-uniform tests: does any lane's cell lie outside the PML-free core / inside the
+// hull of the objects?  (Same skips as the forward kernels.)
+template <typename T>
+__device__ __forceinline__ bool adj_any_pml(const AdjArgs<T>& a, int i, int j, int k) {
+  const bool in_core = i >= a.core[0] && i < a.core[1] && j >= a.core[2] && j < a.core[3] &&
+                       k >= a.core[4] && k < a.core[5];
+  return a.npml > 0 && !__all(in_core);
+}
+template <typename T>
+__device__ __forceinline__ bool adj_any_obj(const AdjArgs<T>& a, int i, int j, int k) {
+  const bool near = i >= a.hull[0] && i < a.hull[1] && j >= a.hull[2] && j < a.hull[3] &&
+                    k >= a.hull[4] && k < a.hull[5];
+  return a.nobj > 0 && __any(near);
+}
+
 // Pass 1 of the adjoint of the E half step.
 template <typename T>
 __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
@@ -63,10 +99,13 @@ __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
   const int j = (int)(r / a.nz), k = (int)(r % a.nz);
   const int64_t c3 = cell * 3;
   T lam[3] = {a.lamF[c3], a.lamF[c3 + 1], a.lamF[c3 + 2]};
-  const T m[3] = {a.mat[c3], a.mat[c3 + 1], a.mat[c3 + 2]};
+  T m[3];
+  adj_material<T>(a, c3, i, j, k, m);
   T G[6] = {0, 0, 0, 0, 0, 0};
+  bool lam_changed = false;
 
   // PML corrections and memory variables (they act on the final E of the half step)
+  if (adj_any_pml(a, i, j, k))
   for (int p = a.npml - 1; p >= 0; --p) {
     const PmlK<T> P = a.pml[p];
     if (P.axis == 0) adj_pml_face<T, 0>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WX_Y], G[WX_Z]);
@@ -76,6 +115,7 @@ __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
 
   // objects, last registered first
   T g[3] = {0, 0, 0};
+  if (adj_any_obj(a, i, j, k))
   for (int o = a.nobj - 1; o >= 0; --o) {
     const ObjK<T> O = a.obj[o];
     if (i < O.x0 || i >= O.x1 || j < O.y0 || j >= O.y1 || k < O.z0 || k >= O.z1) continue;
@@ -91,6 +131,7 @@ __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
         g[c] += ((a.sc * O.inv[oc * 3 + c]) / (T(1) + f)) * lam[c];
         lam[c] *= (T(1) - f) / (T(1) + f);
       }
+      lam_changed = true;
     } else if (O.kind == 3) {
       // forward: E_r += sc * sum_c (M_rc * mod_rc) * cu_c with mod from the traced energies,
       // which are constants of the step (the reference takes them without gradient,
@@ -153,9 +194,11 @@ __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
   T* w = a.work + cell * 6;
 #pragma unroll
   for (int n = 0; n < 6; ++n) w[n] = G[n];
-  a.lamF[c3] = lam[0];
-  a.lamF[c3 + 1] = lam[1];
-  a.lamF[c3 + 2] = lam[2];
+  if (lam_changed) {  // only absorbing objects rescale the field adjoint
+    a.lamF[c3] = lam[0];
+    a.lamF[c3 + 1] = lam[1];
+    a.lamF[c3 + 2] = lam[2];
+  }
 }
 
 // Pass 1 of the adjoint of the H half step (no objects act in that half step).
@@ -169,8 +212,10 @@ __global__ __launch_bounds__(256) void adj_H_cells(AdjArgs<T> a) {
   const int j = (int)(r / a.nz), k = (int)(r % a.nz);
   const int64_t c3 = cell * 3;
   const T lam[3] = {a.lamF[c3], a.lamF[c3 + 1], a.lamF[c3 + 2]};
-  const T m[3] = {a.mat[c3], a.mat[c3 + 1], a.mat[c3 + 2]};
+  T m[3];
+  adj_material<T>(a, c3, i, j, k, m);
   T G[6] = {0, 0, 0, 0, 0, 0};
+  if (adj_any_pml(a, i, j, k))
   for (int p = a.npml - 1; p >= 0; --p) {
     const PmlK<T> P = a.pml[p];
     if (P.axis == 0) adj_pml_face<T, 0>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WX_Y], G[WX_Z]);
