@@ -476,6 +476,22 @@ int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
   // touch the same lines and non-temporal lines are dropped between the two, so plain
   // loads and non-temporal stores; lane mapping makes no measurable difference, flat
   // is used (5.0-5.2 TB/s).
+  // plans with energy-modulated objects (small research grids) run the one kernel that
+  // carries their code
+  bool modulated = false;
+  for (const ObjH& o : p->objs) modulated |= o.kind == FDTDHIP_OBJ_ANISOTROPIC_MODULATED;
+  if (modulated) {
+    const dim3 mgrid(blocks_for((int64_t)(x1 - x0) * plane));
+    if (phaseE) {
+      if (pml) hipLaunchKernelGGL((bulk_E_generic<T, true, true, false, true>), mgrid, block, 0, p->stream, a);
+      else hipLaunchKernelGGL((bulk_E_generic<T, false, true, false, true>), mgrid, block, 0, p->stream, a);
+    } else {
+      if (pml) hipLaunchKernelGGL((bulk_H_generic<T, true, false>), mgrid, block, 0, p->stream, a);
+      else hipLaunchKernelGGL((bulk_H_generic<T, false, false>), mgrid, block, 0, p->stream, a);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   Strategy use = st;
   if (!st.chosen) {
     use.fast = true;
@@ -835,6 +851,8 @@ bool fused_eligible(const fdtdhip_plan* p) {
     return e ? (atoi(e) ? 1 : 0) : -1;
   }();
   if (mode == 0 || !p->E_alt || !p->H_alt) return false;
+  for (const ObjH& o : p->objs)
+    if (o.kind == FDTDHIP_OBJ_ANISOTROPIC_MODULATED) return false;  // only the generic E kernel has them
   if (mode < 0 && (int64_t)p->nx * p->ny * p->nz > FUSED_AUTO_MAX_CELLS) return false;
   if (p->H_below || p->E_above || p->trace_cursor >= 0) return false;
   if (p->nx > 65535 || (int64_t)p->ny * p->nz >= (1ll << 30)) return false;

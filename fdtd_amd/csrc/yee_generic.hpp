@@ -94,7 +94,10 @@ __device__ __forceinline__ bool in_hull(const BulkArgs<T>& a, int i, int j, int 
          k < a.hull[5];
 }
 
-template <typename T, bool HAS_PML, bool HAS_OBJ>
+// HAS_MOD: energy-modulated objects (kind 3) may be present.  Their branch (nine
+// sigmoids) is compiled only into the kernels that run such plans, so that it does not
+// cost the others registers and occupancy.
+template <typename T, bool HAS_PML, bool HAS_OBJ, bool HAS_MOD = false>
 __device__ __forceinline__ void finish_E(const BulkArgs<T>& a, int i, int j, int k,
                                          const Diffs<T>& d, T e[3], const T m[3],
                                          const T hs[3], bool store = true) {
@@ -121,7 +124,7 @@ __device__ __forceinline__ void finish_E(const BulkArgs<T>& a, int i, int j, int
           e[c] *= (T(1) - f) / (T(1) + f);
           e[c] += ((a.sc * O.inv[oc * 3 + c]) * cu[c]) / (T(1) + f);
         }
-      } else if (O.kind == 3) {
+      } else if (HAS_MOD && O.kind == 3) {
         // tensor entries scaled by sigmoid(w_E*sum(E^2) + w_H*sum(H^2) + bias), the
         // energies taken from the fields as they are at this point of the half step
         // (reference fdtd/objects.py:328-349)
@@ -261,7 +264,7 @@ __device__ __forceinline__ int64_t work_block(int64_t blocks_per_plane) {
   return (s / per) * blocks_per_plane + xcd * per + (s % per);
 }
 
-template <typename T, bool HAS_PML, bool HAS_OBJ, bool BAND>
+template <typename T, bool HAS_PML, bool HAS_OBJ, bool BAND, bool HAS_MOD = false>
 __global__ __launch_bounds__(256) void bulk_E_generic(BulkArgs<T> a) {
   const int64_t plane = (int64_t)a.ny * a.nz;
   const int64_t ncell = (int64_t)(a.x1 - a.x0) * plane;
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256) void bulk_E_generic(BulkArgs<T> a) {
   T m[3];
   cell_material<T, false, HAS_OBJ>(a, c3, i, j, k, m);
   const T hs[3] = {hx, hy, hz};
-  finish_E<T, HAS_PML, HAS_OBJ>(a, i, j, k, d, e, m, hs);
+  finish_E<T, HAS_PML, HAS_OBJ, HAS_MOD>(a, i, j, k, d, e, m, hs);
   a.F[c3] = e[0];
   a.F[c3 + 1] = e[1];
   a.F[c3 + 2] = e[2];
