@@ -158,3 +158,21 @@ def test_full_size_translation_invariance(dtype):
         torch.cuda.empty_cache()
     assert float(fields[0][0].abs().max()) > 0
     assert torch.equal(fields[0][0], fields[1][0]) and torch.equal(fields[0][1], fields[1][1])
+
+
+def test_large_grid_kernels_on_small_ragged_shapes():
+    """FDTDHIP_FORCE=1 makes the library use its large-grid kernels whatever the plane
+    size: every golden scene (2-D, 1-D, ragged extents, all boundary orders) must still
+    match the reference.  The switch is read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, FDTDHIP_FORCE="1")
+    done = subprocess.run(
+        [sys.executable, "-m", "pytest", os.path.join(here, "test_hip_parity.py"), "-q", "-x",
+         "-m", "gpu", "-k", "scene_matches_reference", "-p", "no:cacheprovider"],
+        env=env, capture_output=True, text=True, timeout=280, cwd=os.path.dirname(here))
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
+    assert " passed" in done.stdout
