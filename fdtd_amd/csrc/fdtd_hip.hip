@@ -111,6 +111,7 @@ struct DetH {
   int kind;
   int64_t n;
   int64_t* cell = nullptr;  // device flat cell index (CELLS)
+  std::vector<int64_t> cell_host;
   int32_t* xyz = nullptr;   // device (CURRENT)
   double spacing;
   char* outE = nullptr;
@@ -145,6 +146,10 @@ struct fdtdhip_plan {
   bool mat_const[2] = {false, false};
   double mat_bg[2][3] = {{0, 0, 0}, {0, 0, 0}};
   int* scan_flag = nullptr;   // device word the scan kernel raises
+  // cell -> (detector, point) map for the fused step's in-kernel read-out; 0: not built,
+  // 1: built, -1: not possible (shared cells, too many detectors or points)
+  int32_t* detmap = nullptr;
+  int detmap_state = 0;
   int64_t trace_cursor = -1;  // row of the curl traces the next E half step writes; -1: no traces
   std::vector<void*> owned;   // device allocations released by reset/destroy
   // optional kernel timing (fdtdhip_plan_enable_timing)
@@ -179,6 +184,8 @@ int release_tables(fdtdhip_plan* p) {
   p->dets.clear();
   p->obj_dirty = false;
   p->mat_const[0] = p->mat_const[1] = false;
+  p->detmap = nullptr;  // was in `owned`
+  p->detmap_state = 0;
   return 0;
 }
 
@@ -563,7 +570,8 @@ double waveform(const SourceH& s, int64_t q) {
 // interleave plane chunks of the two half steps: boundaries (periodic copies, PMLs
 // registered after a periodic boundary), sources restricted to planes [x0, x1),
 // and the end-of-half-step work (detectors, curl-trace cursor).
-enum { POST_BOUNDARIES = 1, POST_SOURCES = 2, POST_FINISH = 4, POST_ALL = 7 };
+enum { POST_BOUNDARIES = 1, POST_SOURCES = 2, POST_FINISH = 4, POST_ALL = 7,
+       POST_SKIP_CELL_DETECTORS = 8 };
 
 template <typename T>
 int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 = 0, int x1 = -1,
@@ -662,6 +670,7 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
   }
   for (DetH& d : p->dets) {
     if (!(parts & POST_FINISH)) break;
+    if (d.kind == FDTDHIP_DET_CELLS && (parts & POST_SKIP_CELL_DETECTORS)) continue;
     if (d.kind == FDTDHIP_DET_CELLS) {
       int64_t& used = phaseE ? d.usedE : d.usedH;
       char* base = phaseE ? d.outE : d.outH;
@@ -868,10 +877,52 @@ bool fused_eligible(const fdtdhip_plan* p) {
   return points <= MAX_STEP_SOURCES;
 }
 
+// Build the detector map of the fused step once per plan layout.
+int build_detmap(fdtdhip_plan* p) {
+  p->detmap_state = -1;
+  int cells_dets = 0;
+  for (const DetH& d : p->dets)
+    if (d.kind == FDTDHIP_DET_CELLS && d.n > 0) ++cells_dets;
+  if (cells_dets == 0 || cells_dets > MAX_STEP_DETECTORS) return 0;
+  std::vector<int32_t> map((size_t)p->cells(), -1);
+  int slot = 0;
+  for (const DetH& d : p->dets) {
+    if (d.kind != FDTDHIP_DET_CELLS || d.n == 0) continue;
+    if (d.n >= (1 << 24)) return 0;
+    for (int64_t n = 0; n < d.n; ++n) {
+      int32_t& m = map[(size_t)d.cell_host[n]];
+      if (m >= 0) return 0;  // a cell read twice: leave it to the detector kernels
+      m = (slot << 24) | (int32_t)n;
+    }
+    ++slot;
+  }
+  HIPCHK(hipMalloc((void**)&p->detmap, sizeof(int32_t) * map.size()));
+  p->owned.push_back(p->detmap);
+  HIPCHK(hipMemcpy(p->detmap, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice));
+  p->detmap_state = 1;
+  return 0;
+}
+
 template <typename T>
 int fused_step(fdtdhip_plan* p, int64_t q) {
   if (int rc = sync_obj_table<T>(p)) return rc;
+  if (p->detmap_state == 0)
+    if (int rc = build_detmap(p)) return rc;
   StepArgs<T> a;
+  a.detmap = nullptr;
+  if (p->detmap_state == 1) {
+    int slot = 0;
+    for (DetH& d : p->dets) {
+      if (d.kind != FDTDHIP_DET_CELLS || d.n == 0) continue;
+      if (!d.outE || !d.outH || d.usedE >= d.capacity || d.usedH >= d.capacity)
+        return fail(-3, "detector output capacity exhausted");
+      a.detE[slot] = (T*)d.outE + d.usedE * d.n * 3;
+      a.detH[slot] = (T*)d.outH + d.usedH * d.n * 3;
+      ++slot;
+    }
+    for (; slot < MAX_STEP_DETECTORS; ++slot) a.detE[slot] = a.detH[slot] = nullptr;
+    a.detmap = p->detmap;
+  }
   for (int phase = 0; phase < 2; ++phase) {
     const bool phaseE = phase == 0;
     BulkArgs<T>& b = phaseE ? a.e : a.h;
@@ -933,6 +984,13 @@ int fused_step(fdtdhip_plan* p, int64_t q) {
   std::swap(p->E, p->E_alt);
   std::swap(p->H, p->H_alt);
   p->step_flipped = !p->step_flipped;  // psi_E follows through the two fused PML tables
+  if (a.detmap) {
+    // cell-list detectors were read by the kernel; empty ones and loop currents remain
+    for (DetH& d : p->dets) {
+      if (d.kind == FDTDHIP_DET_CELLS) { ++d.usedE; ++d.usedH; }
+    }
+    return post<T>(p, false, q, POST_FINISH | POST_SKIP_CELL_DETECTORS);
+  }
   if (int rc = post<T>(p, true, q, POST_FINISH)) return rc;
   return post<T>(p, false, q, POST_FINISH);
 }
@@ -1255,6 +1313,7 @@ int fdtdhip_plan_add_detector(fdtdhip_plan* p, int kind, int64_t n, const int32_
     std::vector<int64_t> cell((size_t)n);
     for (int64_t i = 0; i < n; ++i)
       cell[i] = (((int64_t)cells[3 * i] * p->ny) + cells[3 * i + 1]) * p->nz + cells[3 * i + 2];
+    d.cell_host = cell;
     if (n > 0) {
       HIPCHK(hipMalloc((void**)&d.cell, sizeof(int64_t) * (size_t)n));
       p->owned.push_back(d.cell);

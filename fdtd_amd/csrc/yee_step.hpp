@@ -40,6 +40,7 @@
 namespace fdtdhip {
 
 constexpr int MAX_STEP_SOURCES = 8;
+constexpr int MAX_STEP_DETECTORS = 4;
 
 template <typename T>
 struct StepArgs {
@@ -50,7 +51,31 @@ struct StepArgs {
   int nsrc;
   int64_t src_elem[MAX_STEP_SOURCES];  // flat element index (cell*3 + component)
   T src_value[MAX_STEP_SOURCES];       // value added to that element of the new E
+  // cell-list detectors read inside the kernel (saves two tiny launches per step):
+  // detmap[cell] = (detector << 24 | point index) or -1; null when they are read by
+  // their own kernels.  detE/detH: this step's reading row of each detector.
+  const int32_t* detmap;
+  T* detE[MAX_STEP_DETECTORS];
+  T* detH[MAX_STEP_DETECTORS];
 };
+
+// The owner lane of a detector cell deposits the step's final E and H there
+// (reference fdtd/detectors.py:114-124: E after the sources, H after the H update).
+template <typename T>
+__device__ __forceinline__ void detect_inline(const StepArgs<T>& a, int64_t c3, const T e[3],
+                                              const T h[3]) {
+  if (!a.detmap) return;
+  const int32_t v = a.detmap[c3 / 3];
+  if (v < 0) return;
+  const int d = v >> 24;
+  const int64_t at = (int64_t)(v & 0xFFFFFF) * 3;
+#pragma unroll
+  for (int n = 0; n < MAX_STEP_DETECTORS; ++n)
+    if (n == d) {
+      a.detE[n][at] = e[0]; a.detE[n][at + 1] = e[1]; a.detE[n][at + 2] = e[2];
+      a.detH[n][at] = h[0]; a.detH[n][at + 1] = h[1]; a.detH[n][at + 2] = h[2];
+    }
+}
 
 template <typename T>
 __device__ __forceinline__ void add_sources(const StepArgs<T>& a, int64_t c3, T e[3]) {
@@ -136,6 +161,7 @@ __global__ __launch_bounds__(256) void step_fused(StepArgs<T> a) {
   cell_material<T, true, false>(a.h, c3, i, j, k, m);
   finish_H<T, HAS_PML>(a.h, i, j, k, d, hc, m);
   store3<T, true>(a.H1 + c3, hc[0], hc[1], hc[2]);
+  detect_inline<T>(a, c3, e, hc);
 }
 
 }  // namespace fdtdhip
