@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (spec)
 
 
-def build_workload(fdtd, name, n_slabs=1, rank=0):
+def build_workload(fdtd, name, n_slabs=1, rank=0, group=None):
     """Returns (grid, cells_per_rank, bytes_per_cell_step, dtype label, description)."""
     import numpy as np
     import torch
@@ -66,7 +66,7 @@ def build_workload(fdtd, name, n_slabs=1, rank=0):
     if n_slabs > 1:
         from fdtd_amd.parallel import SlabGrid
 
-        grid = SlabGrid((shape[0] * n_slabs, shape[1], shape[2]))
+        grid = SlabGrid((shape[0] * n_slabs, shape[1], shape[2]), group=group)
     else:
         grid = fdtd.Grid(shape)
     nx, ny, nz = grid.Nx_global, grid.Ny, grid.Nz  # extents of the whole simulation
@@ -210,30 +210,55 @@ def main():
     backend = os.environ.get("FDTD_DIST_BACKEND", "nccl")
     device = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device)
+    ctl = data_group = None      # control plane (barriers, timing) / halo planes
+    transport = None
     if world > 1:
         import torch.distributed as dist
 
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            ctl = dist.new_group(backend="gloo")   # barriers and the timing reduction on the host
+            transport = "rccl"
+            # one small neighbour exchange over RCCL before anything is built; if it cannot
+            # be done on this machine the planes go through the host instead of the run dying
+            ok = 1
+            try:
+                probe = torch.full((4,), float(rank), device="cuda")
+                got = torch.zeros(4, device="cuda")
+                ops = [dist.P2POp(dist.isend, probe, (rank + 1) % world),
+                       dist.P2POp(dist.irecv, got, (rank - 1) % world)]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                torch.cuda.synchronize()
+                ok = int(float(got[0].item()) == float((rank - 1) % world))
+            except Exception as exc:  # noqa: BLE001 -- any transport failure means "fall back"
+                print(f"rank {rank}: RCCL point-to-point probe failed: {exc}", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)
+            if int(flag.item()) == 0:
+                data_group, transport = ctl, "gloo (host-staged; RCCL point-to-point unavailable)"
         else:
             dist.init_process_group(backend)
+            transport = backend + " (host-staged)"
 
     import fdtd_amd as fdtd
     from fdtd_amd import _lib
 
-    grid, cells, es, dt, desc = build_workload(fdtd, args.workload, world, rank)
+    grid, cells, es, dt, desc = build_workload(fdtd, args.workload, world, rank, data_group)
     lib = _lib.load()
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=ctl)
         torch.cuda.synchronize()
 
     def max_over_ranks(seconds):
         if world == 1:
             return seconds
-        t = torch.tensor([seconds], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([seconds], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
         return float(t.item())
 
     def roofline(ms_e, ms_h, mask, steps):
@@ -285,7 +310,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
             "config": {"workload": desc, "name": args.workload,
                        "parallelism": f"x-slab x{world}" if world > 1 else "single GPU",
-                       "cells_per_gpu": cells},
+                       "cells_per_gpu": cells, **({"transport": transport} if transport else {})},
             "roofline": roof,
         }
     if mask and world == 1 and args.also_arrays:
