@@ -2,8 +2,9 @@
 each other, on a real MI355X.
 
 The library picks its kernels by plane size: grids whose (y, z) plane has 4096 cells
-or more run the unconditional-load kernels (flat or row lane mapping, non-temporal
-access), smaller ones the shape-agnostic kernels the golden scenes exercise.  Here
+or more run the unconditional-load kernels (row lane mapping with rotated z segments
+when the rows fill their 64-lane segments -- the 128- and 192-cell rows below --, flat
+mapping otherwise; non-temporal access), smaller ones the shape-agnostic kernels the golden scenes exercise.  Here
 the grids are large enough for the former and small enough for the numpy oracle to
 follow in seconds; at the benchmark's full size (512^3) the checks are
 size-independent properties: the constant-material and array-material paths agree
@@ -66,7 +67,8 @@ def _build(shape, rs, dense, periodic_y=False):
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("dense", [False, True], ids=["const-materials", "array-materials"])
 @pytest.mark.parametrize("shape,periodic_y", [((26, 70, 66), False), ((24, 150, 30), False),
-                                              ((25, 66, 67), True)])
+                                              ((25, 66, 67), True), ((22, 72, 128), False),
+                                              ((21, 70, 192), True)])
 def test_large_plane_kernels_against_oracle(shape, periodic_y, dense, dtype):
     fdtd.set_backend(f"hip.{dtype}")
     assert shape[1] * shape[2] >= 4096
