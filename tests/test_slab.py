@@ -98,6 +98,12 @@ def test_slabs_equal_single_grid_cpu(scene_name, world, tmp_path):
     _check(scene_name, world, False, tmp_path)
 
 
+def test_five_slabs_cpu(tmp_path):
+    """More ranks than any component is wide: interior ranks with two neighbours, x-PMLs
+    that end inside the first and last slab, objects and line sources cut several times."""
+    _check("slab_mix", 5, False, tmp_path)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene_name", sorted(scenes.SLAB_SCENES))
 def test_slabs_equal_single_grid_gpu(scene_name, tmp_path):
