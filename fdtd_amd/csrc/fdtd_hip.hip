@@ -714,6 +714,13 @@ int curl_launch(const void* in, void* out, int nx, int ny, int nz, bool forward,
 // The adjoint of one half step is: reverse of the post pieces, pass 1 per cell
 // (adjoint_cells), pass 2 gather (adjoint_gather).  On x-slabs the caller exchanges one
 // plane of `work` with a neighbour rank between the two passes.
+// Large planes with well-filled 64-lane row segments take the row lane mapping.
+bool adjoint_rows(const fdtdhip_plan* p) {
+  const int segs = (p->nz + 63) / 64;
+  return (int64_t)p->ny * p->nz >= 4096 && p->nz >= 48 && p->nz * 10 >= segs * 64 * 9 &&
+         p->nx <= 65535 && (p->ny + 3) / 4 <= 65535;
+}
+
 template <typename T>
 int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArgs<T>& a) {
   a.lamF = phaseE ? lamE : lamH;
@@ -739,6 +746,7 @@ int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArg
   BulkArgs<T> boxes;
   fill_core<T>(p, boxes);
   for (int n = 0; n < 6; ++n) { a.hull[n] = boxes.hull[n]; a.core[n] = boxes.core[n]; }
+  a.rot_shift = boxes.rot_shift;
   return 0;
 }
 
@@ -810,9 +818,16 @@ int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
   }
   AdjArgs<T> a;
   if (int rc = adjoint_args<T>(p, phaseE, lamE, lamH, work, a)) return rc;
-  const dim3 grid(blocks_for(p->cells())), block(256);
-  if (phaseE) hipLaunchKernelGGL((adj_E_cells<T>), grid, block, 0, p->stream, a);
-  else hipLaunchKernelGGL((adj_H_cells<T>), grid, block, 0, p->stream, a);
+  const dim3 block(256);
+  if (adjoint_rows(p)) {
+    const dim3 grid((p->nz + 63) / 64, (p->ny + 3) / 4, p->nx);
+    if (phaseE) hipLaunchKernelGGL((adj_E_cells<T, true>), grid, block, 0, p->stream, a);
+    else hipLaunchKernelGGL((adj_H_cells<T, true>), grid, block, 0, p->stream, a);
+  } else {
+    const dim3 grid(blocks_for(p->cells()));
+    if (phaseE) hipLaunchKernelGGL((adj_E_cells<T, false>), grid, block, 0, p->stream, a);
+    else hipLaunchKernelGGL((adj_H_cells<T, false>), grid, block, 0, p->stream, a);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -823,9 +838,16 @@ int adjoint_gather(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, cons
   AdjArgs<T> a;
   if (int rc = adjoint_args<T>(p, phaseE, lamE, lamH, work, a)) return rc;
   a.wghost = wghost;
-  const dim3 grid(blocks_for(p->cells())), block(256);
-  if (phaseE) hipLaunchKernelGGL((adj_gather<T, true>), grid, block, 0, p->stream, a);
-  else hipLaunchKernelGGL((adj_gather<T, false>), grid, block, 0, p->stream, a);
+  const dim3 block(256);
+  if (adjoint_rows(p)) {
+    const dim3 grid((p->nz + 63) / 64, (p->ny + 3) / 4, p->nx);
+    if (phaseE) hipLaunchKernelGGL((adj_gather<T, true, true>), grid, block, 0, p->stream, a);
+    else hipLaunchKernelGGL((adj_gather<T, false, true>), grid, block, 0, p->stream, a);
+  } else {
+    const dim3 grid(blocks_for(p->cells()));
+    if (phaseE) hipLaunchKernelGGL((adj_gather<T, true, false>), grid, block, 0, p->stream, a);
+    else hipLaunchKernelGGL((adj_gather<T, false, false>), grid, block, 0, p->stream, a);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -97,6 +97,7 @@ struct AdjArgs {
   T bg[3];
   int hull[6];         // box containing every object
   int core[6];         // box no PML slab reaches
+  int rot_shift;       // row mapping: z-segment rotation period (as in BulkArgs)
 };
 
 }  // namespace fdtdhip

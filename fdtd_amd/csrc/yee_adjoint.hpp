@@ -19,8 +19,25 @@
 #pragma once
 
 #include "plan.hpp"
+#include "yee_tiled.hpp"
 
 namespace fdtdhip {
+
+// Cell of this lane: ROWS = the half-step row kernel's mapping (a wave per 64-cell z-row
+// segment, 4 rows per workgroup, rotated segments: neighbours stay in the XCD's L2),
+// otherwise one lane per cell of the flattened grid.
+template <typename T, bool ROWS>
+__device__ __forceinline__ bool adj_lane_cell(const AdjArgs<T>& a, int& i, int& j, int& k) {
+  if (ROWS) return lane_cell<false>(0, a.ny, a.nz, a.rot_shift, i, j, k);
+  const int64_t plane = (int64_t)a.ny * a.nz;
+  const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= plane * a.nx) return false;
+  i = (int)(cell / plane);
+  const int64_t r = cell % plane;
+  j = (int)(r / a.nz);
+  k = (int)(r % a.nz);
+  return true;
+}
 
 // order of the six difference adjoints in `work`
 enum { WX_Y = 0, WX_Z = 1, WY_X = 2, WY_Z = 3, WZ_X = 4, WZ_Y = 5 };
@@ -89,14 +106,11 @@ __device__ __forceinline__ bool adj_any_obj(const AdjArgs<T>& a, int i, int j, i
 }
 
 // Pass 1 of the adjoint of the E half step.
-template <typename T>
+template <typename T, bool ROWS>
 __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
-  const int64_t plane = (int64_t)a.ny * a.nz;
-  const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (cell >= plane * a.nx) return;
-  const int i = (int)(cell / plane);
-  const int64_t r = cell % plane;
-  const int j = (int)(r / a.nz), k = (int)(r % a.nz);
+  int i, j, k;
+  if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
+  const int64_t cell = ((int64_t)i * a.ny + j) * a.nz + k;
   const int64_t c3 = cell * 3;
   T lam[3] = {a.lamF[c3], a.lamF[c3 + 1], a.lamF[c3 + 2]};
   T m[3];
@@ -202,14 +216,11 @@ __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
 }
 
 // Pass 1 of the adjoint of the H half step (no objects act in that half step).
-template <typename T>
+template <typename T, bool ROWS>
 __global__ __launch_bounds__(256) void adj_H_cells(AdjArgs<T> a) {
-  const int64_t plane = (int64_t)a.ny * a.nz;
-  const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (cell >= plane * a.nx) return;
-  const int i = (int)(cell / plane);
-  const int64_t r = cell % plane;
-  const int j = (int)(r / a.nz), k = (int)(r % a.nz);
+  int i, j, k;
+  if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
+  const int64_t cell = ((int64_t)i * a.ny + j) * a.nz + k;
   const int64_t c3 = cell * 3;
   const T lam[3] = {a.lamF[c3], a.lamF[c3 + 1], a.lamF[c3 + 2]};
   T m[3];
@@ -239,14 +250,13 @@ __global__ __launch_bounds__(256) void adj_H_cells(AdjArgs<T> a) {
 // Pass 2: transpose of the difference stencil.
 //   E half step: d_a_w(x) = H_w(x) - H_w(x - e_a)  =>  lamH_w(x) += G_a_w(x) - G_a_w(x + e_a)
 //   H half step: d_a_w(x) = E_w(x + e_a) - E_w(x)  =>  lamE_w(x) += G_a_w(x - e_a) - G_a_w(x)
-template <typename T, bool PHASE_E>
+template <typename T, bool PHASE_E, bool ROWS>
 __global__ __launch_bounds__(256) void adj_gather(AdjArgs<T> a) {
+  int i, j, k;
+  if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
   const int64_t plane = (int64_t)a.ny * a.nz;
-  const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (cell >= plane * a.nx) return;
-  const int i = (int)(cell / plane);
-  const int64_t r = cell % plane;
-  const int j = (int)(r / a.nz), k = (int)(r % a.nz);
+  const int64_t r = (int64_t)j * a.nz + k;
+  const int64_t cell = (int64_t)i * plane + r;
   const T* w = a.work + cell * 6;
   const int64_t sx = plane * 6, sy = (int64_t)a.nz * 6, sz = 6;
   auto nb = [&](bool ok, int64_t off, int which) { return ok ? w[off + which] : T(0); };

@@ -159,3 +159,45 @@ def test_cortical_source_forward_without_grad():
                 t.cc_dirs = None
         idle.run(3, progress_bar=False)
         assert torch.isfinite(idle.E).all()
+
+
+def test_large_plane_adjoint_against_finite_differences():
+    """Planes of 64 x 64 cells engage the row-mapped adjoint kernels (and, forward, the
+    large-grid half-step kernels with curl traces): directional derivative against central
+    differences in float64, PMLs on four faces, a learnable and an absorbing object."""
+    fdtd.set_backend("hip.float64")
+    rs = np.random.RandomState(9)
+    shape = (14, 64, 64)
+
+    def build(eps, dM):
+        g = fdtd.Grid(shape)
+        g[0:3, :, :] = fdtd.PML()
+        g[-3:, :, :] = fdtd.PML()
+        g[:, 0:4, :] = fdtd.PML()
+        g[:, :, -4:] = fdtd.PML()
+        obj = fdtd.LearnableAnisotropicObject(permittivity=2.5)
+        g[4:10, 20:40, 10:50] = obj
+        g[5:9, 30:50, 40:60] = fdtd.AbsorbingObject(permittivity=1.5, conductivity=3e4)
+        g[7, 32, 30] = fdtd.PointSource(period=9)
+        with torch.no_grad():
+            obj.inverse_permittivity += eps * dM
+        return g, obj
+
+    def loss_of(g):
+        w = torch.as_tensor(np.random.RandomState(4).rand(*shape, 3), dtype=g.E.dtype, device=g.E.device)
+        return (w * g.E ** 2).sum() + (w * g.H ** 2).sum()
+
+    g0, obj0 = build(0.0, 0.0)
+    dM = fdtd.backend.array(rs.randn(*obj0.inverse_permittivity.shape))
+    g0.run(14, progress_bar=False)
+    loss_of(g0).backward()
+    analytic = (obj0.inverse_permittivity.grad * dM).sum().item()
+    h = 1e-6
+    with torch.no_grad():
+        gp, _ = build(h, dM)
+        gp.run(14, progress_bar=False)
+        gm, _ = build(-h, dM)
+        gm.run(14, progress_bar=False)
+        numeric = (loss_of(gp).item() - loss_of(gm).item()) / (2 * h)
+    assert abs(analytic) > 0
+    assert abs(analytic - numeric) <= 1e-6 * abs(numeric), (analytic, numeric)
