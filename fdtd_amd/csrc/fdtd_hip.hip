@@ -481,8 +481,9 @@ int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
   // materials (a plain 3-read-1-write float4 stream reaches 5.85 TB/s here).
   // float64: cells are 24 B, every load splits in a 16 B and an 8 B instruction that
   // touch the same lines and non-temporal lines are dropped between the two, so plain
-  // loads and non-temporal stores; lane mapping makes no measurable difference, flat
-  // is used (5.0-5.2 TB/s).
+  // loads; the store goes through LDS so that full lines leave the wave (store3_wave),
+  // non-temporal; same row mapping (PMC: 11 % fetch excess against 57 % with the flat
+  // mapping).  5.1 TB/s.
   // plans with energy-modulated objects (small research grids) run the one kernel that
   // carries their code
   bool modulated = false;
@@ -508,7 +509,7 @@ int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
     // quarter of the lanes idle, 68 against 79 Gcells/s) run the flat mapping
     const int segs = (p->nz + 63) / 64;
     const bool ragged = p->nz * 10 < segs * 64 * 9;
-    use.flat = sizeof(T) == 8 || ragged;
+    use.flat = ragged;
   }
   if (use.fast && (st.force || plane >= 4096) && (x1 - x0) <= 65535 && plane < (1ll << 30)) {
     // flat: 256 consecutive cells per workgroup; rows: a wave per z-row segment

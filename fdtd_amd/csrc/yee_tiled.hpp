@@ -41,6 +41,49 @@ __device__ __forceinline__ void store3(T* p, T x, T y, T z) {
   }
 }
 
+// float64 result store through LDS.  A lane's cell is 24 B, which the compiler stores as a
+// 16-byte and an 8-byte instruction: every 64-byte burst of the output then arrives in two
+// partial pieces.  When all 64 lanes of the wave hold consecutive cells (a complete row
+// segment), the wave instead lays its 1536 bytes out in LDS and writes them back as
+// contiguous 16-byte pieces (lane l: piece l, and piece 64+l for l < 32): full lines.
+template <bool NTS>
+__device__ __forceinline__ void store3_wave(double* cell_ptr, double x, double y, double z,
+                                            double* lds_wave) {
+  // (the lanes of a wave always hold consecutive cells of one plane, in both lane mappings)
+  const int lane = threadIdx.x & 63;
+  const bool full = __builtin_amdgcn_read_exec() == ~0ull;
+  if (!full) {
+    store3<double, NTS>(cell_ptr, x, y, z);
+    return;
+  }
+  volatile double* l = lds_wave;
+  l[lane * 3] = x; l[lane * 3 + 1] = y; l[lane * 3 + 2] = z;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  double* out = cell_ptr - lane * 3;   // the wave's first cell
+  const double a0 = l[lane * 2], a1 = l[lane * 2 + 1];
+  if (NTS) {
+    __builtin_nontemporal_store(a0, out + lane * 2);
+    __builtin_nontemporal_store(a1, out + lane * 2 + 1);
+  } else {
+    out[lane * 2] = a0; out[lane * 2 + 1] = a1;
+  }
+  if (lane < 32) {
+    const double b0 = l[128 + lane * 2], b1 = l[128 + lane * 2 + 1];
+    if (NTS) {
+      __builtin_nontemporal_store(b0, out + 128 + lane * 2);
+      __builtin_nontemporal_store(b1, out + 128 + lane * 2 + 1);
+    } else {
+      out[128 + lane * 2] = b0; out[128 + lane * 2 + 1] = b1;
+    }
+  }
+}
+template <bool NTS>
+__device__ __forceinline__ void store3_wave(float* cell_ptr, float x, float y, float z, float*) {
+  store3<float, NTS>(cell_ptr, x, y, z);   // 12-byte cells already store as full lines
+}
+
 // Cell of this lane.  FLAT: 256 consecutive cells of the flattened (y, z) plane per
 // workgroup (grid = blocks per plane x planes); otherwise a wave per z-row segment
 // (grid = z tiles x row quads x planes).
@@ -85,6 +128,7 @@ __global__ __launch_bounds__(256) void bulk_E_rows(BulkArgs<T> a) {
   load3<T, false>(gx, xx, xy, xz);
   load3<T, false>(gy, yx, yy, yz);
   load3<T, false>(gz, zx, zy, zz_);
+  __shared__ T stage[sizeof(T) == 8 ? 4 * 192 : 1];
   T e[3], m[3];
   load3<T, NT>(a.F + c3, e[0], e[1], e[2]);
   cell_material<T, NT, HAS_OBJ>(a, c3, i, j, k, m);
@@ -99,7 +143,7 @@ __global__ __launch_bounds__(256) void bulk_E_rows(BulkArgs<T> a) {
   d.z_y = hasz ? hy - zy : T(0);
   const T hs[3] = {hx, hy, hz};
   finish_E<T, HAS_PML, HAS_OBJ>(a, i, j, k, d, e, m, hs);
-  store3<T, NTS>(a.F + c3, e[0], e[1], e[2]);
+  store3_wave<NTS>(a.F + c3, e[0], e[1], e[2], stage + (threadIdx.x >> 6) * 192);
 }
 
 template <typename T, bool HAS_PML, bool FLAT, bool NT, bool NTS>
@@ -121,6 +165,7 @@ __global__ __launch_bounds__(256) void bulk_H_rows(BulkArgs<T> a) {
   load3<T, false>(gx, xx, xy, xz);
   load3<T, false>(gy, yx, yy, yz);
   load3<T, false>(gz, zx, zy, zz_);
+  __shared__ T stage[sizeof(T) == 8 ? 4 * 192 : 1];
   T h[3], m[3];
   load3<T, NT>(a.F + c3, h[0], h[1], h[2]);
   cell_material<T, NT, false>(a, c3, i, j, k, m);
@@ -134,7 +179,7 @@ __global__ __launch_bounds__(256) void bulk_H_rows(BulkArgs<T> a) {
   d.z_x = hasz ? zx - ex : T(0);
   d.z_y = hasz ? zy - ey : T(0);
   finish_H<T, HAS_PML>(a, i, j, k, d, h, m);
-  store3<T, NTS>(a.F + c3, h[0], h[1], h[2]);
+  store3_wave<NTS>(a.F + c3, h[0], h[1], h[2], stage + (threadIdx.x >> 6) * 192);
 }
 
 }  // namespace fdtdhip
