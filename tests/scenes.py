@@ -191,6 +191,39 @@ SCENES = {
 # fmt: on
 
 
+# edge cases: a yz-plane grid (Nx = 1), PMLs one and two cells thick, an object that fills
+# the grid up to its far faces (reference fdtd/objects.py:77-88: those components keep the
+# grid's value), a diagonal 3-D line source, detectors on the first and last cells, float keys.
+SCENES["edges_yz"] = dict(
+    grid=dict(shape=(1, 23, 19), permittivity=1.2),
+    items=[
+        ("pml",      (S(None), S(0, 1), S(None)), {}),
+        ("pml",      (S(None), S(-2, None), S(None)), {}),
+        ("periodic", (S(None), S(None), -1), {}),
+        ("object",   (S(None), S(4, 23), S(3, 19)), dict(permittivity=("randpos", 17, (1, 19, 16), 1.5, 3.5))),
+        ("line",     (0, S(5, 17), S(4, 16)), dict(period=9, amplitude=0.8)),
+        ("linedet",  (0, S(0, 23), 0), {}),
+        ("blockdet", (0, S(21, 22), S(17, 18)), {}),   # inclusive stops: the last cells
+    ],
+    steps=45,
+)
+SCENES["edges_3d"] = dict(
+    grid=dict(shape=(3.1e-6, 1.7e-6, 1.4e-6), grid_spacing=155e-9),
+    items=[
+        ("pml",       (S(0, 2), S(None), S(None)), dict(a=1e-7)),
+        ("pml",       (S(-1, None), S(None), S(None)), {}),
+        ("pml",       (S(None), S(None), S(0, 1)), {}),
+        ("anisotropic", (S(0, 20), S(0, 11), S(0, 9)), dict(permittivity=1.8), dict(offdiag_seed=31, offdiag_scale=0.02)),  # the whole grid
+        ("absorbing", (S(0.6e-6, 1.5e-6), S(0.3e-6, 0.9e-6), S(2, 7)), dict(permittivity=4.0, conductivity=5e3)),
+        ("line",      (S(3, 17), S(2, 9), S(1, 8)), dict(period=1.2e-14, phase_shift=0.4)),
+        ("point",     (19, 10, 8), dict(period=7)),                     # the last cell
+        ("point",     (0.0, 0.0, 0.0), dict(period=11, amplitude=0.5)), # the first cell, float key
+        ("linedet",   (S(0, 20), S(0, 11), S(0, 9)), {}),               # space diagonal
+        ("currentdet", (S(18, 19), S(9, 10), S(7, 8)), {}),
+    ],
+    steps=40,
+)
+
 # scenes for the x-slab decomposition tests (components straddle the slab faces)
 # probe-fed patch in small (reference tests/test_antenna_impedance.py:17-98): lossy plates,
 # a substrate, and a voltage source with a series resistance fed back from its own loop current
