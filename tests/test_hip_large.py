@@ -178,3 +178,32 @@ def test_large_grid_kernels_on_small_ragged_shapes():
         env=env, capture_output=True, text=True, timeout=280, cwd=os.path.dirname(here))
     assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
     assert " passed" in done.stdout
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_long_run_against_oracle(dtype):
+    """300 steps of a 64 x 96 x 128 grid (row-mapped large-grid kernels, constant materials,
+    six PMLs, an object, a line detector) against the oracle: the tolerances hold after
+    many steps, not just a few (float64 <= 1e-12, float32 <= 1e-5 relative L2)."""
+    fdtd.set_backend(f"hip.{dtype}")
+    shape, steps = (64, 96, 128), 300
+    g, o = fdtd.Grid(shape), orc.OracleGrid(shape)
+    for axis in range(3):
+        for side, key in (("low", slice(0, 8)), ("high", slice(-8, None))):
+            loc = [slice(None)] * 3
+            loc[axis] = key
+            g[tuple(loc)] = fdtd.PML()
+            o.add_pml(axis, side, 8)
+    g[20:40, 30:60, 40:90] = fdtd.Object(permittivity=2.1)
+    o.add_object((20, 40, 30, 60, 40, 90), 2.1)
+    g[32, 48, 30] = fdtd.PointSource(period=17)
+    o.add_point_source((32, 48, 30), period=17)
+    det = fdtd.LineDetector()
+    g[10:54, 48, 64] = det
+    odet = o.add_line_detector(list(range(10, 54)), [48] * 44, [64] * 44)
+    g.run(steps, progress_bar=False)
+    o.run(steps)
+    torch.cuda.synchronize()
+    assert rel_l2(host(g.E), o.E) <= TOL[dtype]
+    assert rel_l2(host(g.H), o.H) <= TOL[dtype]
+    assert rel_l2(host(det.E), np.array(odet.E)) <= TOL[dtype]
