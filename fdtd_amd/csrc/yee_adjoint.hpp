@@ -45,7 +45,7 @@ enum { WX_Y = 0, WX_Z = 1, WY_X = 2, WY_Z = 3, WZ_X = 4, WZ_Y = 5 };
 template <typename T, int AXIS>
 __device__ __forceinline__ void adj_pml_face(const PmlK<T>& P, int nx, int i, int j, int k,
                                              bool phaseE, T sc, const T lam[3], const T m[3],
-                                             T& GdFu, T& GdFv) {
+                                             T& GdFu, T& GdFv, bool store = true) {
   constexpr int u = (AXIS + 1) % 3, v = (AXIS + 2) % 3;
   const int coord = AXIS == 0 ? i : (AXIS == 1 ? j : k);
   const int l = coord - P.lo;
@@ -65,8 +65,10 @@ __device__ __forceinline__ void adj_pml_face(const PmlK<T>& P, int nx, int i, in
     GdFv += P.c[l] * lp0;
     GdFu += P.c[l] * lp1;
   }
-  P.psi[s] = P.b[l] * lp0;
-  P.psi[slab + s] = P.b[l] * lp1;
+  if (store) {
+    P.psi_out[s] = P.b[l] * lp0;
+    P.psi_out[slab + s] = P.b[l] * lp1;
+  }
 }
 
 // Inverse material of a cell for the adjoint kernels: the proven constant (zero under an
@@ -105,26 +107,27 @@ __device__ __forceinline__ bool adj_any_obj(const AdjArgs<T>& a, int i, int j, i
   return a.nobj > 0 && __any(near);
 }
 
-// Pass 1 of the adjoint of the E half step.
-template <typename T, bool ROWS>
-__global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
-  int i, j, k;
-  if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
-  const int64_t cell = ((int64_t)i * a.ny + j) * a.nz + k;
-  const int64_t c3 = cell * 3;
-  T lam[3] = {a.lamF[c3], a.lamF[c3 + 1], a.lamF[c3 + 2]};
+// The adjoint of everything the forward E half step did at one cell after forming the six
+// neighbour differences: on return G holds the adjoints of those differences and lam the
+// adjoint of the cell's E before the half step.  store = false evaluates the cell without
+// side effects (memory-variable adjoints, object gradients), for a lane that needs a
+// neighbour's G.  Returns whether lam changed (only absorbing objects rescale it).
+template <typename T>
+__device__ __forceinline__ bool adj_E_cell(const AdjArgs<T>& a, int i, int j, int k, int64_t c3,
+                                           T lam[3], T G[6], bool store) {
   T m[3];
   adj_material<T>(a, c3, i, j, k, m);
-  T G[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int n = 0; n < 6; ++n) G[n] = T(0);
   bool lam_changed = false;
 
   // PML corrections and memory variables (they act on the final E of the half step)
   if (adj_any_pml(a, i, j, k))
   for (int p = a.npml - 1; p >= 0; --p) {
     const PmlK<T> P = a.pml[p];
-    if (P.axis == 0) adj_pml_face<T, 0>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WX_Y], G[WX_Z]);
-    else if (P.axis == 1) adj_pml_face<T, 1>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WY_Z], G[WY_X]);
-    else adj_pml_face<T, 2>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WZ_X], G[WZ_Y]);
+    if (P.axis == 0) adj_pml_face<T, 0>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WX_Y], G[WX_Z], store);
+    else if (P.axis == 1) adj_pml_face<T, 1>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WY_Z], G[WY_X], store);
+    else adj_pml_face<T, 2>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WZ_X], G[WZ_Y], store);
   }
 
   // objects, last registered first
@@ -164,8 +167,8 @@ __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
           const T mod = T(1) / (T(1) + exp(-(w[0] * eE + w[1] * eH + w[2])));
           g[dcol] += a.sc * ((M[rr * 3 + dcol] * mod) * lam[rr]);
           const T outer = (a.sc * lam[rr]) * cu[dcol];  // dL/d(M_rc * mod_rc)
-          if (O.grad) O.grad[oc * 9 + rr * 3 + dcol] += outer * mod;
-          if (O.gmod) {
+          if (store && O.grad) O.grad[oc * 9 + rr * 3 + dcol] += outer * mod;
+          if (store && O.gmod) {
             const T dz = (outer * M[rr * 3 + dcol]) * (mod * (T(1) - mod));
             T* gm = O.gmod + (oc * 9 + rr * 3 + dcol) * 3;
             gm[0] += dz * eE;
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
         s += M[2 * 3 + dcol] * lam[2];
         g[dcol] += a.sc * s;
       }
-      if (O.grad && O.trace && a.trace_step >= 0) {
+      if (store && O.grad && O.trace && a.trace_step >= 0) {
         const int64_t box = (int64_t)(O.x1 - O.x0) * (O.y1 - O.y0) * (O.z1 - O.z0);
         const T* cu = O.trace + (a.trace_step * box + oc) * 3;
         T* gr = O.grad + oc * 9;
@@ -204,7 +207,19 @@ __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
   if (i == 0 && !a.open_lo) G[WX_Y] = G[WX_Z] = 0;
   if (j == 0) G[WY_X] = G[WY_Z] = 0;
   if (k == 0) G[WZ_X] = G[WZ_Y] = 0;
+  return lam_changed;
+}
 
+// Pass 1 of the adjoint of the E half step.
+template <typename T, bool ROWS>
+__global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
+  int i, j, k;
+  if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
+  const int64_t cell = ((int64_t)i * a.ny + j) * a.nz + k;
+  const int64_t c3 = cell * 3;
+  T lam[3] = {a.lamF[c3], a.lamF[c3 + 1], a.lamF[c3 + 2]};
+  T G[6];
+  const bool lam_changed = adj_E_cell<T>(a, i, j, k, c3, lam, G, true);
   T* w = a.work + cell * 6;
 #pragma unroll
   for (int n = 0; n < 6; ++n) w[n] = G[n];
@@ -215,23 +230,20 @@ __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
   }
 }
 
-// Pass 1 of the adjoint of the H half step (no objects act in that half step).
-template <typename T, bool ROWS>
-__global__ __launch_bounds__(256) void adj_H_cells(AdjArgs<T> a) {
-  int i, j, k;
-  if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
-  const int64_t cell = ((int64_t)i * a.ny + j) * a.nz + k;
-  const int64_t c3 = cell * 3;
-  const T lam[3] = {a.lamF[c3], a.lamF[c3 + 1], a.lamF[c3 + 2]};
+// The same for the H half step (no objects act in that half step).
+template <typename T>
+__device__ __forceinline__ void adj_H_cell(const AdjArgs<T>& a, int i, int j, int k, int64_t c3,
+                                           const T lam[3], T G[6], bool store) {
   T m[3];
   adj_material<T>(a, c3, i, j, k, m);
-  T G[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int n = 0; n < 6; ++n) G[n] = T(0);
   if (adj_any_pml(a, i, j, k))
   for (int p = a.npml - 1; p >= 0; --p) {
     const PmlK<T> P = a.pml[p];
-    if (P.axis == 0) adj_pml_face<T, 0>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WX_Y], G[WX_Z]);
-    else if (P.axis == 1) adj_pml_face<T, 1>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WY_Z], G[WY_X]);
-    else adj_pml_face<T, 2>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WZ_X], G[WZ_Y]);
+    if (P.axis == 0) adj_pml_face<T, 0>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WX_Y], G[WX_Z], store);
+    else if (P.axis == 1) adj_pml_face<T, 1>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WY_Z], G[WY_X], store);
+    else adj_pml_face<T, 2>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WZ_X], G[WZ_Y], store);
   }
   T g[3];
 #pragma unroll
@@ -242,12 +254,27 @@ __global__ __launch_bounds__(256) void adj_H_cells(AdjArgs<T> a) {
   if (i == a.nx - 1 && !a.open_hi) G[WX_Y] = G[WX_Z] = 0;
   if (j == a.ny - 1) G[WY_X] = G[WY_Z] = 0;
   if (k == a.nz - 1) G[WZ_X] = G[WZ_Y] = 0;
+}
+
+// Pass 1 of the adjoint of the H half step.
+template <typename T, bool ROWS>
+__global__ __launch_bounds__(256) void adj_H_cells(AdjArgs<T> a) {
+  int i, j, k;
+  if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
+  const int64_t cell = ((int64_t)i * a.ny + j) * a.nz + k;
+  const int64_t c3 = cell * 3;
+  const T lam[3] = {a.lamF[c3], a.lamF[c3 + 1], a.lamF[c3 + 2]};
+  T G[6];
+  adj_H_cell<T>(a, i, j, k, c3, lam, G, true);
   T* w = a.work + cell * 6;
 #pragma unroll
   for (int n = 0; n < 6; ++n) w[n] = G[n];
 }
 
-// Pass 2: transpose of the difference stencil.
+// Pass 2: transpose of the difference stencil.  (A single-pass form, in which every lane
+// re-derives the difference adjoints of the three neighbours its gather reaches and `work`
+// disappears, was measured: 0.84 ms against 0.79 ms per reverse step at 256^3 -- the four
+// evaluations per cell cost more issue slots than the saved traffic returns -- and dropped.)
 //   E half step: d_a_w(x) = H_w(x) - H_w(x - e_a)  =>  lamH_w(x) += G_a_w(x) - G_a_w(x + e_a)
 //   H half step: d_a_w(x) = E_w(x + e_a) - E_w(x)  =>  lamE_w(x) += G_a_w(x - e_a) - G_a_w(x)
 template <typename T, bool PHASE_E, bool ROWS>

@@ -161,10 +161,12 @@ def test_cortical_source_forward_without_grad():
         assert torch.isfinite(idle.E).all()
 
 
-def test_large_plane_adjoint_against_finite_differences():
+@pytest.mark.parametrize("absorbing", [True, False], ids=["absorbing", "dielectric"])
+def test_large_plane_adjoint_against_finite_differences(absorbing):
     """Planes of 64 x 64 cells engage the row-mapped adjoint kernels (and, forward, the
     large-grid half-step kernels with curl traces): directional derivative against central
-    differences in float64, PMLs on four faces, a learnable and an absorbing object."""
+    differences in float64, PMLs on four faces, a learnable object overlapped by an
+    absorbing or a plain dielectric one."""
     fdtd.set_backend("hip.float64")
     rs = np.random.RandomState(9)
     shape = (14, 64, 64)
@@ -177,7 +179,10 @@ def test_large_plane_adjoint_against_finite_differences():
         g[:, :, -4:] = fdtd.PML()
         obj = fdtd.LearnableAnisotropicObject(permittivity=2.5)
         g[4:10, 20:40, 10:50] = obj
-        g[5:9, 30:50, 40:60] = fdtd.AbsorbingObject(permittivity=1.5, conductivity=3e4)
+        if absorbing:
+            g[5:9, 30:50, 40:60] = fdtd.AbsorbingObject(permittivity=1.5, conductivity=3e4)
+        else:
+            g[5:9, 30:50, 40:60] = fdtd.Object(permittivity=1.5)
         g[7, 32, 30] = fdtd.PointSource(period=9)
         with torch.no_grad():
             obj.inverse_permittivity += eps * dM
@@ -189,15 +194,15 @@ def test_large_plane_adjoint_against_finite_differences():
 
     g0, obj0 = build(0.0, 0.0)
     dM = fdtd.backend.array(rs.randn(*obj0.inverse_permittivity.shape))
-    g0.run(14, progress_bar=False)
+    g0.run(13, progress_bar=False)
     loss_of(g0).backward()
     analytic = (obj0.inverse_permittivity.grad * dM).sum().item()
     h = 1e-6
     with torch.no_grad():
         gp, _ = build(h, dM)
-        gp.run(14, progress_bar=False)
+        gp.run(13, progress_bar=False)
         gm, _ = build(-h, dM)
-        gm.run(14, progress_bar=False)
+        gm.run(13, progress_bar=False)
         numeric = (loss_of(gp).item() - loss_of(gm).item()) / (2 * h)
     assert abs(analytic) > 0
     assert abs(analytic - numeric) <= 1e-6 * abs(numeric), (analytic, numeric)
