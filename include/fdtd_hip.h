@@ -19,8 +19,11 @@
  *   - Small read-only tables (PML profiles, index lists, object descriptors)
  *     are copied into device memory owned by the plan when they are added.
  *   - A plan is not thread safe.  All work is enqueued on the plan's stream
- *     (fdtdhip_plan_set_stream); no call synchronises the device except
- *     fdtdhip_plan_destroy and fdtdhip_plan_reset.
+ *     (fdtdhip_plan_set_stream).  The time-stepping calls do not wait for the
+ *     device, with one exception: the first step after objects or PMLs were added
+ *     or their buffers re-pointed uploads the descriptor tables and waits for that
+ *     copy.  fdtdhip_plan_destroy, fdtdhip_plan_scan_materials and
+ *     fdtdhip_plan_get_timing wait for the stream.
  */
 #ifndef FDTD_HIP_H
 #define FDTD_HIP_H
