@@ -250,7 +250,16 @@ class Grid:
                 "backend on a ROCm device (fdtd_amd.set_backend('hip'))"
             )
         lib = _lib.load()
+        made_for = (bd.native_dtype, bd.device)
+        if self._plan is not None and getattr(self, "_plan_made_for", made_for) != made_for:
+            # set_backend changed precision or device since the plan was made: a plan is
+            # tied to both, the grid's arrays are converted below
+            _lib.check(lib.fdtdhip_plan_destroy(self._plan))
+            self._plan = None
+            self._step_buffers = None
+            self._materials_key = None
         if self._plan is None:
+            self._plan_made_for = made_for
             handle = ctypes.c_void_p()
             _lib.check(lib.fdtdhip_plan_create(
                 ctypes.byref(handle), self.Nx, self.Ny, self.Nz, bd.native_dtype,

@@ -228,3 +228,25 @@ def test_save_data_and_energy_plane(tmp_path, monkeypatch):
     a, b = g3.energy_plane(y=-2)
     assert rel_l2(host(a), (E ** 2).sum(-1)[:, -2, :].T) <= 1e-14
     assert rel_l2(host(b), (H ** 2).sum(-1)[:, -2, :].T) <= 1e-14
+
+
+def test_backend_precision_switch_between_runs():
+    """set_backend after a grid has stepped: the grid follows the new precision (arrays are
+    converted, the native plan is rebuilt for it) and keeps matching the oracle."""
+    fdtd.set_backend("hip.float64")
+    shape = (14, 12, 10)
+    g, o = fdtd.Grid(shape), orc.OracleGrid(shape)
+    g[0:3, :, :] = fdtd.PML()
+    o.add_pml(0, "low", 3)
+    g[4:9, 3:8, 2:7] = fdtd.AbsorbingObject(permittivity=2.0, conductivity=1e3)
+    o.add_object((4, 9, 3, 8, 2, 7), 2.0, kind="absorbing", conductivity=1e3)
+    g[7, 6, 5] = fdtd.PointSource(period=8)
+    o.add_point_source((7, 6, 5), period=8)
+    g.run(10, progress_bar=False); o.run(10)
+    assert rel_l2(host(g.E), o.E) <= 1e-12
+    fdtd.set_backend("hip.float32")
+    g.run(10, progress_bar=False); o.run(10)
+    assert g.E.dtype == torch.float32 and rel_l2(host(g.E), o.E) <= 1e-5
+    fdtd.set_backend("hip.float64")
+    g.run(5, progress_bar=False); o.run(5)
+    assert g.E.dtype == torch.float64 and rel_l2(host(g.H), o.H) <= 1e-5
