@@ -102,6 +102,12 @@ class Object:
 
     def _tensor(self, name):
         t = getattr(self, name)
+        # the kernels index these arrays by the box: a re-bound tensor must keep the shape
+        shapes = self.__dict__.setdefault("_registered_shapes", {})
+        want = shapes.setdefault(name, tuple(t.shape))
+        if tuple(t.shape) != want:
+            raise ValueError(f"{type(self).__name__}.{name} has shape {tuple(t.shape)}; the object "
+                             f"was registered with {want}")
         if t.device != bd.device or t.dtype != bd.float or not t.is_contiguous():
             keep_grad = t.requires_grad
             t = t.detach().to(device=bd.device, dtype=bd.float).contiguous()
