@@ -294,6 +294,12 @@ class Grid:
         _lib.check(lib.fdtdhip_plan_set_step_buffers(
             self._plan, alt[0].data_ptr() if alt else None, alt[1].data_ptr() if alt else None))
         lo, hi = self._halo
+        if any(t is not None and (t.dtype != bd.float or t.device != bd.device) for t in (lo, hi)):
+            lo, hi = (None if t is None else t.to(device=bd.device, dtype=bd.float).contiguous()
+                      for t in (lo, hi))
+            self._halo = (lo, hi)
+            if hasattr(self, "_H_below"):
+                self._H_below, self._E_above = lo, hi
         _lib.check(lib.fdtdhip_plan_set_halo(
             self._plan, lo.data_ptr() if lo is not None else None,
             hi.data_ptr() if hi is not None else None))
