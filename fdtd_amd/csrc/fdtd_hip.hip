@@ -382,6 +382,12 @@ void fill_core(const fdtdhip_plan* p, BulkArgs<T>& a) {
     else c[2 * h.axis + 1] = std::min(c[2 * h.axis + 1], h.lo);
   }
   for (int n = 0; n < 6; ++n) a.core[n] = c[n];
+  for (int n = 0; n < MAX_PML; ++n) {
+    const bool have = n < (int)p->pmls.size();
+    a.face_axis[n] = have ? p->pmls[n].axis : 0;
+    a.face_lo[n] = have ? p->pmls[n].lo : 0;
+    a.face_hi[n] = have ? p->pmls[n].lo + p->pmls[n].t : 0;
+  }
   int h[6] = {p->nx, 0, p->ny, 0, p->nz, 0};
   for (const ObjH& o : p->objs)
     for (int ax = 0; ax < 3; ++ax) {
@@ -673,6 +679,17 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
                          phaseE ? s.compE : s.compH, (T)(s.amplitude * w));
     }
   }
+  // cell-list detectors share launches (up to MAX_DET_BATCH per launch); reading a field
+  // does not change it, so their order among the detectors does not matter
+  DetBatch<T> batch;
+  batch.count = 0;
+  batch.first[0] = 0;
+  auto flush = [&]() {
+    if (batch.count == 0) return;
+    hipLaunchKernelGGL((detect_cells_batch<T>), dim3(blocks_for(batch.first[batch.count])),
+                       dim3(256), 0, p->stream, F, batch);
+    batch.count = 0;
+  };
   for (DetH& d : p->dets) {
     if (!(parts & POST_FINISH)) break;
     if (d.kind == FDTDHIP_DET_CELLS && (parts & POST_SKIP_CELL_DETECTORS)) continue;
@@ -680,20 +697,22 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
       int64_t& used = phaseE ? d.usedE : d.usedH;
       char* base = phaseE ? d.outE : d.outH;
       if (d.n == 0) { ++used; continue; }
-      if (!base || used >= d.capacity) return fail(-3, "detector output capacity exhausted");
-      T* out = (T*)base + used * d.n * 3;
-      hipLaunchKernelGGL((detect_cells<T>), dim3(blocks_for(d.n * 3)), dim3(256), 0, p->stream, F,
-                         d.cell, out, d.n);
+      if (!base || used >= d.capacity) { flush(); return fail(-3, "detector output capacity exhausted"); }
+      batch.cell[batch.count] = d.cell;
+      batch.out[batch.count] = (T*)base + used * d.n * 3;
+      batch.first[batch.count + 1] = batch.first[batch.count] + d.n * 3;
+      if (++batch.count == MAX_DET_BATCH) flush();
       ++used;
     } else if (!phaseE) {
       if (d.n == 0) { ++d.usedH; continue; }
-      if (!d.outH || d.usedH >= d.capacity) return fail(-3, "detector output capacity exhausted");
+      if (!d.outH || d.usedH >= d.capacity) { flush(); return fail(-3, "detector output capacity exhausted"); }
       T* out = (T*)d.outH + d.usedH * d.n;
       hipLaunchKernelGGL((detect_current<T>), dim3(blocks_for(d.n, 64)), dim3(64), 0, p->stream,
                          (const T*)p->H, d.xyz, out, d.n, p->nx, p->ny, p->nz, (T)d.spacing);
       ++d.usedH;
     }
   }
+  flush();
   HIPCHK(hipGetLastError());
   return 0;
 }

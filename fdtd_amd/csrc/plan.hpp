@@ -71,6 +71,10 @@ struct BulkArgs {
                        // with no cell inside it skips the object table
   int core[6];         // x0,x1,y0,y1,z0,z1 of the box no PML slab reaches: a wavefront whose
                        // cells all lie inside it skips the PML table altogether
+  // Normal axis and index range [lo, hi) of each PML face, in table order: a wavefront
+  // near some slab tests every face against these (already in scalar registers with the
+  // other arguments) and reads from the table only the descriptors of faces it touches.
+  int face_axis[MAX_PML], face_lo[MAX_PML], face_hi[MAX_PML];
 };
 
 // Arguments of the adjoint (reverse-time) half-step kernels.  For the adjoint of

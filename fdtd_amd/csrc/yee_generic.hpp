@@ -75,7 +75,14 @@ __device__ __forceinline__ void pml_all(const BulkArgs<T>& a, int i, int j, int 
   const bool in_core = i >= a.core[0] && i < a.core[1] && j >= a.core[2] && j < a.core[3] &&
                        k >= a.core[4] && k < a.core[5];
   if (__all(in_core)) return;
-  for (int p = 0; p < a.npml; ++p) {
+  // (a wave that waits for one table entry per face, touched or not, lives about a fifth
+  // longer; with a third of all waves near some slab that was 5 % of the 512^3 step)
+#pragma unroll
+  for (int p = 0; p < MAX_PML; ++p) {
+    if (p >= a.npml) break;
+    const int ax = a.face_axis[p];
+    const int coord = ax == 0 ? i : (ax == 1 ? j : k);
+    if (!__any(coord >= a.face_lo[p] && coord < a.face_hi[p])) continue;
     const PmlK<T> P = a.pml[p];
     if (P.axis == 0) pml_face<T, 0>(P, a.nx, i, j, k, d.x_y, d.x_z, PHASE_E, a.sc, f, m, store);
     else if (P.axis == 1) pml_face<T, 1>(P, a.nx, i, j, k, d.y_z, d.y_x, PHASE_E, a.sc, f, m, store);
@@ -463,12 +470,27 @@ __global__ void source_soft_point(T* E, int64_t elem, const double* wave, int64_
   if (vout_out) vout_out[0] = (T)vout;
 }
 
-// Cell-list detector (reference fdtd/detectors.py:117, 123, 250, 263).
+// Cell-list detectors (reference fdtd/detectors.py:117, 123, 250, 263): out[t] =
+// F[cell[t / 3]][t % 3].  Several detectors share a launch: detector d owns the threads
+// [first[d], first[d+1]) and reads its own cell list into its own output row.
+constexpr int MAX_DET_BATCH = 8;
 template <typename T>
-__global__ void detect_cells(const T* F, const int64_t* cell, T* out, int64_t n) {
+struct DetBatch {
+  const int64_t* cell[MAX_DET_BATCH];
+  T* out[MAX_DET_BATCH];
+  int64_t first[MAX_DET_BATCH + 1];  // in values (3 per cell)
+  int count;
+};
+template <typename T>
+__global__ void detect_cells_batch(const T* F, DetBatch<T> b) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * 3) return;
-  out[t] = F[cell[t / 3] * 3 + (t % 3)];
+  if (t >= b.first[b.count]) return;
+#pragma unroll
+  for (int d = 0; d < MAX_DET_BATCH; ++d)
+    if (d < b.count && t >= b.first[d] && t < b.first[d + 1]) {
+      const int64_t u = t - b.first[d];
+      b.out[d][u] = F[b.cell[d][u / 3] * 3 + (u % 3)];
+    }
 }
 
 // Loop-current detector (reference fdtd/detectors.py:443-462), including the
