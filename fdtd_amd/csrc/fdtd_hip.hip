@@ -1187,6 +1187,12 @@ int fdtdhip_plan_add_periodic(fdtdhip_plan* p, int axis) {
   if (axis == FDTDHIP_PERIODIC_X_EXTERNAL)
     for (const BoundaryRef& b : p->boundaries)
       if (b.kind == 1 && b.idx == axis) return fail(-1, "one external periodic boundary at most");
+  // Along an axis of one cell the first and the last plane are the same plane and the copy
+  // (reference fdtd/boundaries.py:177-208) changes nothing: the usual z boundary of 2-D
+  // grids.  Not recorded, so that such grids keep the one-launch step and the PMLs listed
+  // after it keep their correction inside the bulk kernel.
+  const int extent[3] = {p->nx, p->ny, p->nz};
+  if (axis < 3 && extent[axis] == 1) return 0;
   p->boundaries.push_back({1, axis});
   return 0;
 }

@@ -51,6 +51,13 @@ __device__ __forceinline__ void pml_face(const PmlK<T>& P, int nx, int i, int j,
 template <typename T>
 struct Diffs;
 
+// Inside the box that no PML slab reaches.
+template <typename T>
+__device__ __forceinline__ bool in_core(const BulkArgs<T>& a, int i, int j, int k) {
+  return i >= a.core[0] && i < a.core[1] && j >= a.core[2] && j < a.core[3] && k >= a.core[4] &&
+         k < a.core[5];
+}
+
 // All PML faces of the plan, in registration order.  The descriptors live in a small
 // device table read at wave-uniform addresses (scalar loads), one face at a time, so
 // that the loop costs no vector registers.
@@ -72,9 +79,7 @@ struct Diffs {
 template <typename T, bool PHASE_E>
 __device__ __forceinline__ void pml_all(const BulkArgs<T>& a, int i, int j, int k,
                                         const Diffs<T>& d, T f[3], const T m[3], bool store) {
-  const bool in_core = i >= a.core[0] && i < a.core[1] && j >= a.core[2] && j < a.core[3] &&
-                       k >= a.core[4] && k < a.core[5];
-  if (__all(in_core)) return;
+  if (__all(in_core(a, i, j, k))) return;
   // (a wave that waits for one table entry per face, touched or not, lives about a fifth
   // longer; with a third of all waves near some slab that was 5 % of the 512^3 step)
 #pragma unroll
@@ -94,16 +99,86 @@ __device__ __forceinline__ void pml_all(const BulkArgs<T>& a, int i, int j, int 
 // cell: curl, grid update, objects in registration order, PML memory update
 // and correction.  `e` holds the cell's E on entry and the new E on return.
 // store = false evaluates the cell without side effects (no memory-variable or trace
-// writes): used when a lane re-derives a neighbour's new E in the fused full step.
+// writes).
+// Inside the box that contains every object.
 template <typename T>
 __device__ __forceinline__ bool in_hull(const BulkArgs<T>& a, int i, int j, int k) {
   return i >= a.hull[0] && i < a.hull[1] && j >= a.hull[2] && j < a.hull[3] && k >= a.hull[4] &&
          k < a.hull[5];
 }
 
+// One object acting on one cell in the E half step (reference fdtd/objects.py:116-126,
+// 204-218, 251-266, 328-349); nothing happens outside its box.  cu: curl of H at the cell.
 // HAS_MOD: energy-modulated objects (kind 3) may be present.  Their branch (nine
 // sigmoids) is compiled only into the kernels that run such plans, so that it does not
 // cost the others registers and occupancy.
+template <typename T, bool HAS_MOD>
+__device__ __forceinline__ void apply_object(const BulkArgs<T>& a, const ObjK<T>& O, int i, int j,
+                                             int k, const T cu[3], T e[3], const T hs[3],
+                                             bool store) {
+  if (i < O.x0 || i >= O.x1 || j < O.y0 || j >= O.y1 || k < O.z0 || k >= O.z1) return;
+  const int64_t oc =
+      ((int64_t)(i - O.x0) * (O.y1 - O.y0) + (j - O.y0)) * (O.z1 - O.z0) + (k - O.z0);
+  if (O.kind == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) e[c] += (a.sc * O.inv[oc * 3 + c]) * cu[c];
+  } else if (O.kind == 1) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const T f = O.absorb[oc * 3 + c];
+      e[c] *= (T(1) - f) / (T(1) + f);
+      e[c] += ((a.sc * O.inv[oc * 3 + c]) * cu[c]) / (T(1) + f);
+    }
+  } else if (HAS_MOD && O.kind == 3) {
+    // tensor entries scaled by sigmoid(w_E*sum(E^2) + w_H*sum(H^2) + bias), the
+    // energies taken from the fields as they are at this point of the half step
+    // (reference fdtd/objects.py:328-349)
+    const T eE = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+    const T eH = hs[0] * hs[0] + hs[1] * hs[1] + hs[2] * hs[2];
+    if (store && a.trace_step >= 0) {
+      const int64_t box = (int64_t)(O.x1 - O.x0) * (O.y1 - O.y0) * (O.z1 - O.z0);
+      if (O.trace) {
+        T* tr = O.trace + (a.trace_step * box + oc) * 3;
+        tr[0] = cu[0]; tr[1] = cu[1]; tr[2] = cu[2];
+      }
+      if (O.etrace) {
+        T* et = O.etrace + (a.trace_step * box + oc) * 2;
+        et[0] = eE; et[1] = eH;
+      }
+    }
+    T add[3];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+      const T* M = O.inv + oc * 9 + rr * 3;
+      T s = T(0);
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        const T* w = O.modw + (rr * 3 + cc) * 3;
+        const T mod = T(1) / (T(1) + exp(-(w[0] * eE + w[1] * eH + w[2])));
+        s += (M[cc] * mod) * cu[cc];
+      }
+      add[rr] = a.sc * s;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) e[rr] += add[rr];
+  } else {
+    if (store && O.trace && a.trace_step >= 0) {  // differentiable run: keep the curl
+      const int64_t box =
+          (int64_t)(O.x1 - O.x0) * (O.y1 - O.y0) * (O.z1 - O.z0);
+      T* tr = O.trace + (a.trace_step * box + oc) * 3;
+      tr[0] = cu[0]; tr[1] = cu[1]; tr[2] = cu[2];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+      const T* M = O.inv + oc * 9 + rr * 3;
+      T s = M[0] * cu[0];
+      s += M[1] * cu[1];
+      s += M[2] * cu[2];
+      e[rr] += a.sc * s;
+    }
+  }
+}
+
 template <typename T, bool HAS_PML, bool HAS_OBJ, bool HAS_MOD = false>
 __device__ __forceinline__ void finish_E(const BulkArgs<T>& a, int i, int j, int k,
                                          const Diffs<T>& d, T e[3], const T m[3],
@@ -118,67 +193,7 @@ __device__ __forceinline__ void finish_E(const BulkArgs<T>& a, int i, int j, int
   if (HAS_OBJ && __any(in_hull(a, i, j, k))) {
     for (int o = 0; o < a.nobj; ++o) {
       const ObjK<T> O = a.obj[o];
-      if (i < O.x0 || i >= O.x1 || j < O.y0 || j >= O.y1 || k < O.z0 || k >= O.z1) continue;
-      const int64_t oc =
-          ((int64_t)(i - O.x0) * (O.y1 - O.y0) + (j - O.y0)) * (O.z1 - O.z0) + (k - O.z0);
-      if (O.kind == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) e[c] += (a.sc * O.inv[oc * 3 + c]) * cu[c];
-      } else if (O.kind == 1) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const T f = O.absorb[oc * 3 + c];
-          e[c] *= (T(1) - f) / (T(1) + f);
-          e[c] += ((a.sc * O.inv[oc * 3 + c]) * cu[c]) / (T(1) + f);
-        }
-      } else if (HAS_MOD && O.kind == 3) {
-        // tensor entries scaled by sigmoid(w_E*sum(E^2) + w_H*sum(H^2) + bias), the
-        // energies taken from the fields as they are at this point of the half step
-        // (reference fdtd/objects.py:328-349)
-        const T eE = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
-        const T eH = hs[0] * hs[0] + hs[1] * hs[1] + hs[2] * hs[2];
-        if (store && a.trace_step >= 0) {
-          const int64_t box = (int64_t)(O.x1 - O.x0) * (O.y1 - O.y0) * (O.z1 - O.z0);
-          if (O.trace) {
-            T* tr = O.trace + (a.trace_step * box + oc) * 3;
-            tr[0] = cu[0]; tr[1] = cu[1]; tr[2] = cu[2];
-          }
-          if (O.etrace) {
-            T* et = O.etrace + (a.trace_step * box + oc) * 2;
-            et[0] = eE; et[1] = eH;
-          }
-        }
-        T add[3];
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
-          const T* M = O.inv + oc * 9 + rr * 3;
-          T s = T(0);
-#pragma unroll
-          for (int cc = 0; cc < 3; ++cc) {
-            const T* w = O.modw + (rr * 3 + cc) * 3;
-            const T mod = T(1) / (T(1) + exp(-(w[0] * eE + w[1] * eH + w[2])));
-            s += (M[cc] * mod) * cu[cc];
-          }
-          add[rr] = a.sc * s;
-        }
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr) e[rr] += add[rr];
-      } else {
-        if (store && O.trace && a.trace_step >= 0) {  // differentiable run: keep the curl
-          const int64_t box =
-              (int64_t)(O.x1 - O.x0) * (O.y1 - O.y0) * (O.z1 - O.z0);
-          T* tr = O.trace + (a.trace_step * box + oc) * 3;
-          tr[0] = cu[0]; tr[1] = cu[1]; tr[2] = cu[2];
-        }
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
-          const T* M = O.inv + oc * 9 + rr * 3;
-          T s = M[0] * cu[0];
-          s += M[1] * cu[1];
-          s += M[2] * cu[2];
-          e[rr] += a.sc * s;
-        }
-      }
+      apply_object<T, HAS_MOD>(a, O, i, j, k, cu, e, hs, store);
     }
   }
 

@@ -61,54 +61,219 @@ struct StepArgs {
 
 // The owner lane of a detector cell deposits the step's final E and H there
 // (reference fdtd/detectors.py:114-124: E after the sources, H after the H update).
+// v: the cell's entry of the detector map (-1: no detector reads the cell), fetched at
+// the start of the kernel so that its latency is not added at the end.
 template <typename T>
-__device__ __forceinline__ void detect_inline(const StepArgs<T>& a, int64_t c3, const T e[3],
+__device__ __forceinline__ void detect_inline(const StepArgs<T>& a, int32_t v, const T e[3],
                                               const T h[3]) {
-  if (!a.detmap) return;
-  const int32_t v = a.detmap[c3 / 3];
   if (v < 0) return;
   const int d = v >> 24;
   const int64_t at = (int64_t)(v & 0xFFFFFF) * 3;
+  T* oe = a.detE[0];
+  T* oh = a.detH[0];
 #pragma unroll
-  for (int n = 0; n < MAX_STEP_DETECTORS; ++n)
-    if (n == d) {
-      a.detE[n][at] = e[0]; a.detE[n][at + 1] = e[1]; a.detE[n][at + 2] = e[2];
-      a.detH[n][at] = h[0]; a.detH[n][at + 1] = h[1]; a.detH[n][at + 2] = h[2];
-    }
+  for (int n = 1; n < MAX_STEP_DETECTORS; ++n) {
+    oe = n == d ? a.detE[n] : oe;
+    oh = n == d ? a.detH[n] : oh;
+  }
+  oe[at] = e[0]; oe[at + 1] = e[1]; oe[at + 2] = e[2];
+  oh[at] = h[0]; oh[at + 1] = h[1]; oh[at + 2] = h[2];
 }
 
+// A lane evaluates the E update of up to four cells: its own (index 0, the only one whose
+// side effects are kept) and its forward x, y and z neighbours.  The four evaluations
+// run side by side -- one walk over the object table and one over the PML faces for all
+// of them, the loads of all cells requested before any is used -- because on the small
+// grids this kernel serves a step is one short-lived wave per SIMD and its time is the
+// length of the chain of dependent memory round trips, not the amount of work.
+constexpr int STEP_CELLS = 4;
+
 template <typename T>
-__device__ __forceinline__ void add_sources(const StepArgs<T>& a, int64_t c3, T e[3]) {
+struct StepCell {
+  int i, j, k;
+  int c3;        // flat element offset of the cell (small grids: fits 32 bits)
+  bool live;     // false: the neighbour does not exist (or is the cell itself); not evaluated
+  Diffs<T> d;
+  T cu[3], e[3], m[3], hs[3];
+};
+
+// Additive point sources on the new E of the cells (reference fdtd/grid.py:293-295).
+template <typename T>
+__device__ __forceinline__ void add_sources(const StepArgs<T>& a, StepCell<T> (&c)[STEP_CELLS]) {
 #pragma unroll
   for (int n = 0; n < MAX_STEP_SOURCES; ++n) {
     if (n >= a.nsrc) break;
-    const int64_t off = a.src_elem[n] - c3;
-    if (off == 0) e[0] += a.src_value[n];
-    else if (off == 1) e[1] += a.src_value[n];
-    else if (off == 2) e[2] += a.src_value[n];
+    const int elem = (int)a.src_elem[n];
+    bool hit = false;
+#pragma unroll
+    for (int q = 0; q < STEP_CELLS; ++q) hit |= c[q].live && (unsigned)(elem - c[q].c3) < 3u;
+    if (hit) {
+#pragma unroll
+      for (int q = 0; q < STEP_CELLS; ++q) {
+        const int off = c[q].live ? elem - c[q].c3 : -1;
+        const T v = a.src_value[n];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {   // a choice between values, not between addresses
+          const T old = c[q].e[x];
+          c[q].e[x] = off == x ? old + v : old;
+        }
+      }
+    }
   }
 }
 
-// New E of cell (i,j,k) whose flat element offset is c3.  hc: H0 at the cell; hxm,
-// hym, hzm: H0 at the backward neighbours (any value where that neighbour does not
-// exist).
-template <typename T, bool HAS_PML, bool HAS_OBJ, bool OWNER>
-__device__ __forceinline__ void new_E(const StepArgs<T>& a, int i, int j, int k, int64_t c3,
-                                      const T hc[3], const T hxm[3], const T hym[3],
-                                      const T hzm[3], T e[3]) {
-  Diffs<T> d;
+// One PML face acting on the cells in the E half step: the arithmetic of pml_face, with
+// the memory variables and profiles of every cell requested before any is used.  The
+// normal axis is a run-time (wave-uniform) value here: one copy of the code per face of
+// the unrolled face loop instead of three.
+template <typename T>
+__device__ __forceinline__ void pml_face_cells(const PmlK<T>& P, int nx, T sc,
+                                               StepCell<T> (&c)[STEP_CELLS]) {
+  const int axis = P.axis;
+  const int64_t slab = (int64_t)(axis == 0 ? P.t : nx) * P.sy * P.sz;
+  bool in[STEP_CELLS];
+  int l[STEP_CELLS];
+  int64_t s[STEP_CELLS];
+  T b[STEP_CELLS], cc[STEP_CELLS], p0[STEP_CELLS], p1[STEP_CELLS];
+#pragma unroll
+  for (int q = 0; q < STEP_CELLS; ++q) {
+    // (values are copied out of the cell before any choice between them: a choice
+    // between two members would become a run-time address into the cell array and
+    // push the whole array out of registers)
+    const int qi = c[q].i, qj = c[q].j, qk = c[q].k;
+    const int coord = axis == 0 ? qi : (axis == 1 ? qj : qk);
+    l[q] = coord - P.lo;
+    in[q] = c[q].live && l[q] >= 0 && l[q] < P.t;
+    b[q] = cc[q] = p0[q] = p1[q] = T(0);
+    s[q] = 0;
+    if (in[q]) {
+      const int li = axis == 0 ? l[q] : qi, lj = axis == 1 ? l[q] : qj,
+                lk = axis == 2 ? l[q] : qk;
+      s[q] = ((int64_t)li * P.sy + lj) * P.sz + lk;
+      b[q] = P.b[l[q]];
+      cc[q] = P.c[l[q]];
+      p0[q] = P.psi[s[q]];
+      p1[q] = P.psi[slab + s[q]];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < STEP_CELLS; ++q) {
+    if (in[q]) {
+      // u = (axis+1)%3 takes -psi[0], v = (axis+2)%3 takes psi[1]; the differences along
+      // the axis of components u and v drive psi[1] and psi[0]
+      const T dxy = c[q].d.x_y, dxz = c[q].d.x_z, dyx = c[q].d.y_x, dyz = c[q].d.y_z,
+              dzx = c[q].d.z_x, dzy = c[q].d.z_y;
+      const T dFu = axis == 0 ? dxy : (axis == 1 ? dyz : dzx);
+      const T dFv = axis == 0 ? dxz : (axis == 1 ? dyx : dzy);
+      T q0 = p0[q] * b[q], q1 = p1[q] * b[q];
+      if (l[q] >= 1) { q0 += dFv * cc[q]; q1 += dFu * cc[q]; }
+      if (q == 0) {
+        P.psi_out[s[q]] = q0;
+        P.psi_out[slab + s[q]] = q1;
+      }
+      if (P.fused) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+          const bool is_u = x == (axis + 1) % 3, is_v = x == (axis + 2) % 3;
+          const T f = sc * c[q].m[x], old = c[q].e[x];
+          const T with_u = old + f * (-q0), with_v = old + f * q1;
+          c[q].e[x] = is_u ? with_u : (is_v ? with_v : old);
+        }
+      }
+    }
+  }
+}
+
+// The E update of the cells: materials, curl, grid update, objects in registration order,
+// PML faces in registration order, sources -- per cell the operations of finish_E.
+template <typename T, bool HAS_PML, bool HAS_OBJ>
+__device__ __forceinline__ void new_E_cells(const StepArgs<T>& a, StepCell<T> (&c)[STEP_CELLS]) {
+  const BulkArgs<T>& A = a.e;
+  bool hull = false, core = true;
+#pragma unroll
+  for (int q = 0; q < STEP_CELLS; ++q) {
+    if (HAS_OBJ) hull |= c[q].live && in_hull(A, c[q].i, c[q].j, c[q].k);
+    if (HAS_PML) core &= !c[q].live || in_core(A, c[q].i, c[q].j, c[q].k);
+  }
+  const bool obj_near = HAS_OBJ && __any(hull), pml_near = HAS_PML && !__all(core);
+
+  // old E and the inverse permittivity of every cell
+#pragma unroll
+  for (int q = 0; q < STEP_CELLS; ++q)
+    if (c[q].live) load3<T, false>(A.F + c[q].c3, c[q].e[0], c[q].e[1], c[q].e[2]);
+  if (A.mat_const) {
+    bool covered[STEP_CELLS] = {false, false, false, false};
+    if (obj_near)
+      for (int o = 0; o < A.nobj; ++o) {
+        const ObjK<T> O = A.obj[o];
+#pragma unroll
+        for (int q = 0; q < STEP_CELLS; ++q)
+          covered[q] |= c[q].i >= O.x0 && c[q].i < O.x1 && c[q].j >= O.y0 && c[q].j < O.y1 &&
+                        c[q].k >= O.z0 && c[q].k < O.z1;
+      }
+#pragma unroll
+    for (int q = 0; q < STEP_CELLS; ++q)
+#pragma unroll
+      for (int x = 0; x < 3; ++x) c[q].m[x] = covered[q] ? T(0) : A.bg[x];
+  } else {
+#pragma unroll
+    for (int q = 0; q < STEP_CELLS; ++q)
+      if (c[q].live) load3<T, false>(A.mat + c[q].c3, c[q].m[0], c[q].m[1], c[q].m[2]);
+  }
+
+#pragma unroll
+  for (int q = 0; q < STEP_CELLS; ++q) {
+    c[q].cu[0] = c[q].d.y_z - c[q].d.z_y;
+    c[q].cu[1] = c[q].d.z_x - c[q].d.x_z;
+    c[q].cu[2] = c[q].d.x_y - c[q].d.y_x;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) c[q].e[x] += (A.sc * c[q].m[x]) * c[q].cu[x];
+  }
+
+  if (obj_near)
+    for (int o = 0; o < A.nobj; ++o) {
+      const ObjK<T> O = A.obj[o];
+#pragma unroll
+      for (int q = 0; q < STEP_CELLS; ++q)
+        if (c[q].live)
+          apply_object<T, false>(A, O, c[q].i, c[q].j, c[q].k, c[q].cu, c[q].e, c[q].hs, q == 0);
+    }
+
+  if (pml_near) {
+#pragma unroll
+    for (int p = 0; p < MAX_PML; ++p) {
+      if (p >= A.npml) break;
+      const int ax = A.face_axis[p];
+      bool hit = false;
+#pragma unroll
+      for (int q = 0; q < STEP_CELLS; ++q) {
+        const int qi = c[q].i, qj = c[q].j, qk = c[q].k;
+        const int coord = ax == 0 ? qi : (ax == 1 ? qj : qk);
+        hit |= c[q].live && coord >= A.face_lo[p] && coord < A.face_hi[p];
+      }
+      if (__any(hit)) {
+        const PmlK<T> P = A.pml[p];
+        pml_face_cells<T>(P, A.nx, A.sc, c);
+      }
+    }
+  }
+  add_sources<T>(a, c);
+}
+
+template <typename T>
+__device__ __forceinline__ void set_cell(StepCell<T>& c, bool live, int i, int j, int k, int c3,
+                                         const T hc[3], const T hxm[3], const T hym[3],
+                                         const T hzm[3]) {
+  c.live = live; c.i = i; c.j = j; c.k = k; c.c3 = c3;
   const bool hasx = i > 0, hasy = j > 0, hasz = k > 0;
-  d.x_y = hasx ? hc[1] - hxm[1] : T(0);
-  d.x_z = hasx ? hc[2] - hxm[2] : T(0);
-  d.y_x = hasy ? hc[0] - hym[0] : T(0);
-  d.y_z = hasy ? hc[2] - hym[2] : T(0);
-  d.z_x = hasz ? hc[0] - hzm[0] : T(0);
-  d.z_y = hasz ? hc[1] - hzm[1] : T(0);
-  T m[3];
-  load3<T, false>(a.e.F + c3, e[0], e[1], e[2]);
-  cell_material<T, false, HAS_OBJ>(a.e, c3, i, j, k, m);
-  finish_E<T, HAS_PML, HAS_OBJ>(a.e, i, j, k, d, e, m, hc, OWNER);
-  add_sources<T>(a, c3, e);
+  c.d.x_y = hasx ? hc[1] - hxm[1] : T(0);
+  c.d.x_z = hasx ? hc[2] - hxm[2] : T(0);
+  c.d.y_x = hasy ? hc[0] - hym[0] : T(0);
+  c.d.y_z = hasy ? hc[2] - hym[2] : T(0);
+  c.d.z_x = hasz ? hc[0] - hzm[0] : T(0);
+  c.d.z_y = hasz ? hc[1] - hzm[1] : T(0);
+#pragma unroll
+  for (int x = 0; x < 3; ++x) { c.hs[x] = hc[x]; c.e[x] = T(0); }
 }
 
 template <typename T, bool HAS_PML, bool HAS_OBJ>
@@ -116,14 +281,15 @@ __global__ __launch_bounds__(256) void step_fused(StepArgs<T> a) {
   int i, j, k;
   if (!lane_cell<true>(0, a.e.ny, a.e.nz, 0, i, j, k)) return;
   const int nx = a.e.nx, ny = a.e.ny, nz = a.e.nz;
-  const int64_t sz = 3, sy = 3 * (int64_t)nz, sx = sy * ny;
-  const int64_t c3 = (int64_t)i * sx + (int64_t)j * sy + 3 * k;
+  const int sz = 3, sy = 3 * nz, sx = sy * ny;      // small grids: element offsets fit 32 bits
+  const int c3 = i * sx + j * sy + 3 * k;
   const T* __restrict__ H0 = a.e.G + c3;
+  const int32_t det = a.detmap ? a.detmap[c3 / 3] : -1;
 
   // neighbour offsets, clamped to the cell itself where the neighbour does not exist
-  const int64_t xm = i > 0 ? -sx : 0, ym = j > 0 ? -sy : 0, zm = k > 0 ? -sz : 0;
+  const int xm = i > 0 ? -sx : 0, ym = j > 0 ? -sy : 0, zm = k > 0 ? -sz : 0;
   const bool hasxp = i < nx - 1, hasyp = j < ny - 1, haszp = k < nz - 1;
-  const int64_t xp = hasxp ? sx : 0, yp = hasyp ? sy : 0, zp = haszp ? sz : 0;
+  const int xp = hasxp ? sx : 0, yp = hasyp ? sy : 0, zp = haszp ? sz : 0;
 
   T hc[3], hxm[3], hym[3], hzm[3], hxp[3], hyp[3], hzp[3];
   T hxpym[3], hxpzm[3], hypxm[3], hypzm[3], hzpxm[3], hzpym[3];
@@ -141,27 +307,29 @@ __global__ __launch_bounds__(256) void step_fused(StepArgs<T> a) {
   load3<T, false>(H0 + zp + xm, hzpxm[0], hzpxm[1], hzpxm[2]);
   load3<T, false>(H0 + zp + ym, hzpym[0], hzpym[1], hzpym[2]);
 
-  // new E at the cell (owner: stores psi_E) and at its forward neighbours
-  T e[3], ex[3], ey[3], ez[3];
-  new_E<T, HAS_PML, HAS_OBJ, true>(a, i, j, k, c3, hc, hxm, hym, hzm, e);
-  new_E<T, HAS_PML, HAS_OBJ, false>(a, i + (hasxp ? 1 : 0), j, k, c3 + xp, hxp, hc, hxpym, hxpzm, ex);
-  new_E<T, HAS_PML, HAS_OBJ, false>(a, i, j + (hasyp ? 1 : 0), k, c3 + yp, hyp, hypxm, hc, hypzm, ey);
-  new_E<T, HAS_PML, HAS_OBJ, false>(a, i, j, k + (haszp ? 1 : 0), c3 + zp, hzp, hzpxm, hzpym, hc, ez);
+  // new E at the cell (index 0: stores psi_E) and at its forward neighbours
+  StepCell<T> c[STEP_CELLS];
+  set_cell<T>(c[0], true, i, j, k, c3, hc, hxm, hym, hzm);
+  set_cell<T>(c[1], hasxp, i + (hasxp ? 1 : 0), j, k, c3 + xp, hxp, hc, hxpym, hxpzm);
+  set_cell<T>(c[2], hasyp, i, j + (hasyp ? 1 : 0), k, c3 + yp, hyp, hypxm, hc, hypzm);
+  set_cell<T>(c[3], haszp, i, j, k + (haszp ? 1 : 0), c3 + zp, hzp, hzpxm, hzpym, hc);
+  new_E_cells<T, HAS_PML, HAS_OBJ>(a, c);
+  const T* e = c[0].e;
   store3<T, true>(a.E1 + c3, e[0], e[1], e[2]);
 
   // H half step at the cell from the new E (forward differences, dropped at the high edges)
   Diffs<T> d;
-  d.x_y = hasxp ? ex[1] - e[1] : T(0);
-  d.x_z = hasxp ? ex[2] - e[2] : T(0);
-  d.y_x = hasyp ? ey[0] - e[0] : T(0);
-  d.y_z = hasyp ? ey[2] - e[2] : T(0);
-  d.z_x = haszp ? ez[0] - e[0] : T(0);
-  d.z_y = haszp ? ez[1] - e[1] : T(0);
+  d.x_y = hasxp ? c[1].e[1] - e[1] : T(0);
+  d.x_z = hasxp ? c[1].e[2] - e[2] : T(0);
+  d.y_x = hasyp ? c[2].e[0] - e[0] : T(0);
+  d.y_z = hasyp ? c[2].e[2] - e[2] : T(0);
+  d.z_x = haszp ? c[3].e[0] - e[0] : T(0);
+  d.z_y = haszp ? c[3].e[1] - e[1] : T(0);
   T m[3];
   cell_material<T, true, false>(a.h, c3, i, j, k, m);
   finish_H<T, HAS_PML>(a.h, i, j, k, d, hc, m);
   store3<T, true>(a.H1 + c3, hc[0], hc[1], hc[2]);
-  detect_inline<T>(a, c3, e, hc);
+  detect_inline<T>(a, det, e, hc);
 }
 
 }  // namespace fdtdhip

@@ -483,12 +483,13 @@ class Grid:
     def _provide_step_buffers(self):
         """Second E/H (and PML psi_E) buffers that let ``run`` use the fused full-step
         kernel; allocated once, and only for scenes the native library can fuse (no
-        periodic boundary, no plane source, few additive source points)."""
+        periodic boundary other than along an axis of one cell, where the copy is the
+        identity; no plane source; few additive source points)."""
         if getattr(self, "_step_buffers", None) is not None or self.Nx != self.Nx_global:
             return
         points = 0
         for b in self.boundaries:
-            if not hasattr(b, "thickness"):
+            if not hasattr(b, "thickness") and self.shape[b.axis] != 1:
                 return
         for s in self.sources:
             if not hasattr(s, "_wave_args"):
@@ -498,7 +499,7 @@ class Grid:
             return
         self._step_buffers = (torch.empty_like(self.E.detach()), torch.empty_like(self.H.detach()))
         for b in self.boundaries:
-            if b._active and getattr(b, "_psiE_alt", None) is None:
+            if hasattr(b, "thickness") and b._active and getattr(b, "_psiE_alt", None) is None:
                 b._psiE_alt = torch.empty_like(b._psiE.detach())
 
     def run(self, total_time: Number, progress_bar: bool = True):
