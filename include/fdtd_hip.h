@@ -108,7 +108,9 @@ int fdtdhip_plan_add_pml(fdtdhip_plan* plan, int axis, int side, int thickness,
                          const double* cH, void* psiE, void* psiH);
 
 /* Periodic boundary along `axis` (reference fdtd/boundaries.py:173-208); axis may be
- * FDTDHIP_PERIODIC_X_EXTERNAL (see fdtdhip_update_E_post_stage). */
+ * FDTDHIP_PERIODIC_X_EXTERNAL (see fdtdhip_update_E_post_stage).  Along an axis of one
+ * cell the copy maps a plane onto itself (boundaries.py:177, 182 with index 0 == -1); it
+ * is accepted and not recorded. */
 #define FDTDHIP_PERIODIC_X_EXTERNAL 3
 int fdtdhip_plan_add_periodic(fdtdhip_plan* plan, int axis);
 
