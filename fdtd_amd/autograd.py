@@ -191,6 +191,8 @@ def differentiable_advance(grid, n):
             raise NotImplementedError(f"differentiable runs do not cover {src._no_autograd}")
     objs, pmls = _learnable(grid), _active_pmls(grid)
     grid._fields()
+    if n >= 2:
+        grid._provide_step_buffers()   # small grids: one launch per recorded step as well
     inputs = [o.inverse_permittivity for o in objs]
     for o in _modulated(objs):
         inputs += [o.nonlin_conv.weight, o.nonlin_conv.bias]

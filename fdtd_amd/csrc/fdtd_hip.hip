@@ -584,6 +584,14 @@ double waveform(const SourceH& s, int64_t q) {
 enum { POST_BOUNDARIES = 1, POST_SOURCES = 2, POST_FINISH = 4, POST_ALL = 7,
        POST_SKIP_CELL_DETECTORS = 8 };
 
+// The E pass of a step filled one row of the objects' curl traces.
+void advance_trace_cursor(fdtdhip_plan* p) {
+  if (p->trace_cursor < 0) return;
+  ++p->trace_cursor;
+  for (const ObjH& o : p->objs)
+    if (o.trace && p->trace_cursor >= o.trace_capacity) p->trace_cursor = -1;  // traces full
+}
+
 template <typename T>
 int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 = 0, int x1 = -1,
          int stage = -1) {
@@ -593,11 +601,7 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
   if (x1 < 0) x1 = p->nx;
   const int64_t plane3 = (int64_t)p->ny * p->nz * 3;
   const int64_t elem_lo = x0 * plane3, elem_hi = x1 * plane3;
-  if ((parts & POST_FINISH) && phaseE && p->trace_cursor >= 0) {
-    ++p->trace_cursor;  // the E bulk pass of this step filled one trace row
-    for (const ObjH& o : p->objs)
-      if (o.trace && p->trace_cursor >= o.trace_capacity) p->trace_cursor = -1;  // traces full
-  }
+  if ((parts & POST_FINISH) && phaseE) advance_trace_cursor(p);
   // stage 0 / 1: only what precedes / follows the x-periodic boundary whose copy crosses
   // ranks (the caller performs it in between); sources and the rest belong to stage 1
   size_t ext = p->boundaries.size();
@@ -909,7 +913,7 @@ bool fused_eligible(const fdtdhip_plan* p) {
   for (const ObjH& o : p->objs)
     if (o.kind == FDTDHIP_OBJ_ANISOTROPIC_MODULATED) return false;  // only the generic E kernel has them
   if (mode < 0 && (int64_t)p->nx * p->ny * p->nz > FUSED_AUTO_MAX_CELLS) return false;
-  if (p->H_below || p->E_above || p->trace_cursor >= 0) return false;
+  if (p->H_below || p->E_above) return false;
   if (p->nx > 65535 || (int64_t)p->ny * p->nz >= (1ll << 30)) return false;
   for (const BoundaryRef& b : p->boundaries)
     if (b.kind == 1) return false;
@@ -982,7 +986,7 @@ int fused_step(fdtdhip_plan* p, int64_t q) {
     b.npml = (int)p->pmls.size();
     b.nobj = phaseE ? (int)p->objs.size() : 0;
     b.obj = (const ObjK<T>*)p->obj_table;
-    b.trace_step = -1;
+    b.trace_step = phaseE ? p->trace_cursor : -1;   // the owner lane records the curl
     fill_core<T>(p, b);
     fill_material<T>(p, phaseE, b);
   }
@@ -1035,6 +1039,7 @@ int fused_step(fdtdhip_plan* p, int64_t q) {
     for (DetH& d : p->dets) {
       if (d.kind == FDTDHIP_DET_CELLS) { ++d.usedE; ++d.usedH; }
     }
+    advance_trace_cursor(p);
     return post<T>(p, false, q, POST_FINISH | POST_SKIP_CELL_DETECTORS);
   }
   if (int rc = post<T>(p, true, q, POST_FINISH)) return rc;
