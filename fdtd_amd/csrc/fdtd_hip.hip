@@ -150,6 +150,8 @@ struct fdtdhip_plan {
   // 1: built, -1: not possible (shared cells, too many detectors or points)
   int32_t* detmap = nullptr;
   int detmap_state = 0;
+  void* adj_work = nullptr;   // second `work` array of the paired adjoint launches (owned)
+  int64_t adj_work_bytes = 0;
   int64_t trace_cursor = -1;  // row of the curl traces the next E half step writes; -1: no traces
   std::vector<void*> owned;   // device allocations released by reset/destroy
   // optional kernel timing (fdtdhip_plan_enable_timing)
@@ -186,6 +188,8 @@ int release_tables(fdtdhip_plan* p) {
   p->mat_const[0] = p->mat_const[1] = false;
   p->detmap = nullptr;  // was in `owned`
   p->detmap_state = 0;
+  p->adj_work = nullptr;  // was in `owned`
+  p->adj_work_bytes = 0;
   return 0;
 }
 
@@ -876,11 +880,67 @@ int adjoint_gather(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, cons
   return 0;
 }
 
+// The paired adjoint launches serve plans in which nothing acts on the field adjoints
+// between a gather and the next cell pass: no recorded periodic boundary (and hence no PML
+// whose correction follows one), only additive point sources (no adjoint of their own).
+bool adjoint_pairs_eligible(const fdtdhip_plan* p) {
+  static const int mode = [] {
+    const char* e = getenv("FDTDHIP_FUSED");
+    return e ? (atoi(e) ? 1 : 0) : -1;
+  }();
+  if (mode == 0) return false;
+  if (mode < 0 && p->cells() > (int64_t)(1 << 19)) return false;
+  if (adjoint_rows(p)) return false;   // (never true below 2^19 cells by default; keeps the flat mapping)
+  for (const BoundaryRef& b : p->boundaries)
+    if (b.kind == 1) return false;
+  for (const PmlH& h : p->pmls)
+    if (!h.fused) return false;
+  for (const SourceH& s : p->sources)
+    if (s.kind != FDTDHIP_SRC_ADD_POINTS) return false;
+  return true;
+}
+
 template <typename T>
 int adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH, void* work) {
   if (!p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
   if (p->H_below || p->E_above)
     return fail(-1, "x-slabs: drive fdtdhip_adjoint_cells / fdtdhip_adjoint_gather per half step");
+  if (adjoint_pairs_eligible(p)) {
+    // small grids: the gather of one half step and the cell pass of the next in one
+    // launch (adj_gather_then_cells), alternating between two work arrays
+    const int64_t bytes = p->cells() * 6 * (int64_t)sizeof(T);
+    if (p->adj_work_bytes < bytes) {
+      void* w2 = nullptr;
+      HIPCHK(hipMalloc(&w2, (size_t)bytes));
+      p->owned.push_back(w2);
+      p->adj_work = w2;
+      p->adj_work_bytes = bytes;
+    }
+    if (int rc = sync_obj_table<T>(p)) return rc;
+    T* wa = (T*)work;
+    T* wb = (T*)p->adj_work;
+    const dim3 grid(blocks_for(p->cells())), block(256);
+    p->trace_cursor = nsteps - 1;
+    if (int rc = adjoint_cells<T>(p, false, (T*)lamE, (T*)lamH, wa)) return rc;   // H of the last step
+    for (int64_t s = nsteps - 1; s >= 0; --s) {
+      AdjArgs<T> g, c;
+      p->trace_cursor = s;
+      // gather of the H half step (completes lamE) + cell pass of the E half step
+      if (int rc = adjoint_args<T>(p, false, (T*)lamE, (T*)lamH, wa, g)) return rc;
+      if (int rc = adjoint_args<T>(p, true, (T*)lamE, (T*)lamH, wb, c)) return rc;
+      hipLaunchKernelGGL((adj_gather_then_cells<T, false>), grid, block, 0, p->stream, g, c);
+      if (s == 0) break;
+      // gather of the E half step (completes lamH) + cell pass of the H half step before it
+      if (int rc = adjoint_args<T>(p, true, (T*)lamE, (T*)lamH, wb, g)) return rc;
+      if (int rc = adjoint_args<T>(p, false, (T*)lamE, (T*)lamH, wa, c)) return rc;
+      hipLaunchKernelGGL((adj_gather_then_cells<T, true>), grid, block, 0, p->stream, g, c);
+    }
+    HIPCHK(hipGetLastError());
+    p->trace_cursor = 0;
+    if (int rc = adjoint_gather<T>(p, true, (T*)lamE, (T*)lamH, wb, (const T*)nullptr)) return rc;
+    p->trace_cursor = -1;
+    return 0;
+  }
   for (int64_t s = nsteps - 1; s >= 0; --s) {
     p->trace_cursor = s;
     for (int phase = 0; phase < 2; ++phase) {  // undo the H half step, then the E half step

@@ -277,10 +277,9 @@ __global__ __launch_bounds__(256) void adj_H_cells(AdjArgs<T> a) {
 // evaluations per cell cost more issue slots than the saved traffic returns -- and dropped.)
 //   E half step: d_a_w(x) = H_w(x) - H_w(x - e_a)  =>  lamH_w(x) += G_a_w(x) - G_a_w(x + e_a)
 //   H half step: d_a_w(x) = E_w(x + e_a) - E_w(x)  =>  lamE_w(x) += G_a_w(x - e_a) - G_a_w(x)
-template <typename T, bool PHASE_E, bool ROWS>
-__global__ __launch_bounds__(256) void adj_gather(AdjArgs<T> a) {
-  int i, j, k;
-  if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
+template <typename T, bool PHASE_E>
+__device__ __forceinline__ void adj_gather_cell(const AdjArgs<T>& a, int i, int j, int k,
+                                                T add[3]) {
   const int64_t plane = (int64_t)a.ny * a.nz;
   const int64_t r = (int64_t)j * a.nz + k;
   const int64_t cell = (int64_t)i * plane + r;
@@ -292,7 +291,6 @@ __global__ __launch_bounds__(256) void adj_gather(AdjArgs<T> a) {
     if (inside) return w[off + which];
     return open && a.wghost ? a.wghost[r * 6 + which] : T(0);
   };
-  T add[3];
   if (PHASE_E) {
     const bool ox = i < a.nx - 1, oy = j < a.ny - 1, oz = k < a.nz - 1;
     add[0] = (w[WY_X] - nb(oy, sy, WY_X)) + (w[WZ_X] - nb(oz, sz, WZ_X));
@@ -304,10 +302,49 @@ __global__ __launch_bounds__(256) void adj_gather(AdjArgs<T> a) {
     add[1] = (nbx(ox, -sx, a.open_lo, WX_Y) - w[WX_Y]) + (nb(oz, -sz, WZ_Y) - w[WZ_Y]);
     add[2] = (nbx(ox, -sx, a.open_lo, WX_Z) - w[WX_Z]) + (nb(oy, -sy, WY_Z) - w[WY_Z]);
   }
+}
+
+template <typename T, bool PHASE_E, bool ROWS>
+__global__ __launch_bounds__(256) void adj_gather(AdjArgs<T> a) {
+  int i, j, k;
+  if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
+  const int64_t cell = ((int64_t)i * a.ny + j) * a.nz + k;
+  T add[3];
+  adj_gather_cell<T, PHASE_E>(a, i, j, k, add);
   T* out = a.lamG + cell * 3;
   out[0] += add[0];
   out[1] += add[1];
   out[2] += add[2];
+}
+
+// Small grids (one wave per SIMD, time = number of launches): pass 2 of one half step and
+// pass 1 of the half step undone next, in one launch.  The gather completes the cell's
+// adjoint of the field that the next pass 1 starts from, and pass 1 is local to the cell,
+// so the only new requirement is that the two passes use different `work` arrays (other
+// lanes still gather from the one being read).  g: arguments of the gather (its lamG is
+// the field adjoint completed here); c: arguments of the pass 1 that follows (c.lamF is
+// that same array, c.work the other work array).  GATHER_E: the gather belongs to the
+// adjoint of the E half step and the pass 1 to that of the H half step of the step before.
+template <typename T, bool GATHER_E>
+__global__ __launch_bounds__(256) void adj_gather_then_cells(AdjArgs<T> g, AdjArgs<T> c) {
+  int i, j, k;
+  if (!adj_lane_cell<T, false>(g, i, j, k)) return;
+  const int64_t cell = ((int64_t)i * g.ny + j) * g.nz + k;
+  const int64_t c3 = cell * 3;
+  T add[3];
+  adj_gather_cell<T, GATHER_E>(g, i, j, k, add);
+  T lam[3] = {g.lamG[c3], g.lamG[c3 + 1], g.lamG[c3 + 2]};
+#pragma unroll
+  for (int n = 0; n < 3; ++n) lam[n] += add[n];
+  T G[6];
+  if (GATHER_E) adj_H_cell<T>(c, i, j, k, c3, lam, G, true);
+  else adj_E_cell<T>(c, i, j, k, c3, lam, G, true);
+  T* w = c.work + cell * 6;
+#pragma unroll
+  for (int n = 0; n < 6; ++n) w[n] = G[n];
+  c.lamF[c3] = lam[0];
+  c.lamF[c3 + 1] = lam[1];
+  c.lamF[c3 + 2] = lam[2];
 }
 
 // Adjoint of pml_apply_slab (a PML whose correction follows a periodic copy):
