@@ -218,7 +218,15 @@ def main():
         import torch.distributed as dist
 
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            # RCCL's stream gets high priority: a halo plane's send/recv kernel should start as
+            # soon as it is enqueued, not queue behind the interior kernel it is meant to overlap
+            opts = None
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+            except Exception:  # noqa: BLE001 -- an option of convenience only
+                opts = None
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device), pg_options=opts)
             ctl = dist.new_group(backend="gloo")   # barriers and the timing reduction on the host
             transport = "rccl"
             # one small neighbour exchange over RCCL before anything is built; if it cannot

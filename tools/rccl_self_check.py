@@ -11,7 +11,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
 torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+opts = dist.ProcessGroupNCCL.Options()
+opts.is_high_priority_stream = True     # as bench.py initialises RCCL
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0),
+                        pg_options=opts)
 import fdtd_amd as fdtd
 from fdtd_amd.parallel import SlabGrid
 
