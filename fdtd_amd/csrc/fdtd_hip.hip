@@ -905,6 +905,7 @@ int adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH, void* w
   if (!p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
   if (p->H_below || p->E_above)
     return fail(-1, "x-slabs: drive fdtdhip_adjoint_cells / fdtdhip_adjoint_gather per half step");
+  if (nsteps <= 0) return 0;
   if (adjoint_pairs_eligible(p)) {
     // small grids: the gather of one half step and the cell pass of the next in one
     // launch (adj_gather_then_cells), alternating between two work arrays
