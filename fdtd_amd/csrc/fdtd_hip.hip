@@ -959,13 +959,16 @@ int adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH, void* w
 // kernel cannot do itself: no periodic boundary, no hard plane source, no x-slab
 // halo, no curl trace being recorded, at most MAX_STEP_SOURCES additive source points
 // without repeated cells, and the caller has provided the second buffers.
-constexpr int64_t FUSED_AUTO_MAX_CELLS = 1 << 19;
+constexpr int64_t FUSED_AUTO_MAX_CELLS = 1 << 17;
 
 bool fused_eligible(const fdtdhip_plan* p) {
-  // FDTDHIP_FUSED=0 never, =1 whenever possible; by default only for grids small
-  // enough that launch count, not memory traffic, sets the step time (the fused
-  // kernel reads more through L1 than the two half-step kernels and is slower on
-  // large grids: 512^3 fp32 3.2 ms against 2.2 ms).
+  // FDTDHIP_FUSED=0 never, =1 whenever possible.  By default only where it was measured
+  // faster than two half-step launches (MI355X, PML on every face, tools/mid_cost.py):
+  // 2-D grids up to about 420 x 420 cells (161 x 97: 9.0 against 11.4 us per step,
+  // 360^2: 12.7 / 14.1, 420^2: 15.4 / 15.7, 512^2: 17.7 / 17.1).  In 3-D the lane's four
+  // E evaluations with six faces cost more than the second launch at every size tried
+  // (32^3: 14.6 against 12.6 us, 48^3: 17.1 / 15.7, 80^3: 49 / 30), and on large grids the
+  // kernel is L1-bound (512^3 fp32: 3.2 ms against 2.2 ms).
   static const int mode = [] {
     const char* e = getenv("FDTDHIP_FUSED");
     return e ? (atoi(e) ? 1 : 0) : -1;
@@ -973,7 +976,8 @@ bool fused_eligible(const fdtdhip_plan* p) {
   if (mode == 0 || !p->E_alt || !p->H_alt) return false;
   for (const ObjH& o : p->objs)
     if (o.kind == FDTDHIP_OBJ_ANISOTROPIC_MODULATED) return false;  // only the generic E kernel has them
-  if (mode < 0 && (int64_t)p->nx * p->ny * p->nz > FUSED_AUTO_MAX_CELLS) return false;
+  if (mode < 0 && (p->cells() > FUSED_AUTO_MAX_CELLS || std::min(p->nx, std::min(p->ny, p->nz)) > 1))
+    return false;
   if (p->H_below || p->E_above) return false;
   if (p->nx > 65535 || (int64_t)p->ny * p->nz >= (1ll << 30)) return false;
   for (const BoundaryRef& b : p->boundaries)

@@ -180,6 +180,29 @@ def test_large_grid_kernels_on_small_ragged_shapes():
     assert " passed" in done.stdout
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_one_launch_step_forced_on_and_off(fused):
+    """By default the library takes the one-launch step for small 2-D grids only.
+    FDTDHIP_FUSED=1 applies it wherever the plan allows (3-D scenes too), FDTDHIP_FUSED=0
+    nowhere: every golden scene must match the reference either way, and so must the
+    differentiable runs (the one-launch step records their curl traces; the paired adjoint
+    launches follow the same switch).  Read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, FDTDHIP_FUSED=fused)
+    done = subprocess.run(
+        [sys.executable, "-m", "pytest", os.path.join(here, "test_hip_parity.py"),
+         os.path.join(here, "test_adjoint.py"), "-q", "-x", "-m", "gpu",
+         "-k", "scene_matches_reference or gradients_match_reference_autograd or finite_differences",
+         "-p", "no:cacheprovider"],
+        env=env, capture_output=True, text=True, timeout=280, cwd=os.path.dirname(here))
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
+    assert " passed" in done.stdout
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_long_run_against_oracle(dtype):
     """300 steps of a 64 x 96 x 128 grid (row-mapped large-grid kernels, constant materials,
