@@ -1,0 +1,31 @@
+#!/bin/bash
+# HBM-traffic counters of the bulk kernels of one bench workload: one rocprofv3 pass per
+# counter (FETCH_SIZE, WRITE_SIZE), the program being python3 itself.
+# usage: tools/pmc_bench.sh <workload> [bench args]     -> gpurun_out/pmc_<workload>.txt
+set -e
+cd "$(dirname "$0")/.."
+w=$1; shift
+out=gpurun_out/pmc_$w
+rm -rf "$out"; mkdir -p "$out"
+export TMPDIR=/tmp
+for grp in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 240 rocprofv3 --pmc $grp --output-format csv -d "$out/$grp" -- python3 bench.py --workload "$w" --no-cpu-baseline --steps 10 --warmup 2 "$@" > "$out/$grp.log" 2>&1 || { echo "pass $grp failed"; tail -3 "$out/$grp.log"; exit 1; }
+done
+python3 - "$out" "$w" <<'PY' | tee gpurun_out/pmc_$w.txt
+import csv, glob, sys, collections
+out, w = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row.get("Kernel_Name", "")
+        if "fdtdhip::bulk" not in k: continue
+        agg["E" if "bulk_E" in k else "H"][row["Counter_Name"]].append(float(row["Counter_Value"]))
+tot = {}
+for name in sorted(agg):
+    for c, v in sorted(agg[name].items()):
+        v = v[len(v)//2:]  # later launches (steady state)
+        tot.setdefault(c, []).append(sum(v)/len(v))
+        print(f"{w} bulk_{name} {c}: mean {sum(v)/len(v):.6g} KB over {len(v)} launches")
+f = sum(tot["FETCH_SIZE"]) / len(tot["FETCH_SIZE"]); wr = sum(tot["WRITE_SIZE"]) / len(tot["WRITE_SIZE"])
+print(f"{w} per launch (mean of E and H): FETCH_SIZE {f:.0f} KB, WRITE_SIZE {wr:.0f} KB, bytes = (2*FETCH+WRITE)*1024 = {(2*f+wr)*1024:.0f}")
+PY
