@@ -1,0 +1,142 @@
+"""Seeded random scenes in the format of ``tests/scenes.py``: random shapes (1-D to 3-D,
+ragged extents), boundaries on random faces in random registration order, overlapping
+objects of every kind, sources and detectors of every kind.  Every scene is valid input
+for the reference's API (no construction errors) and short enough to stay finite.
+
+Used by ``tools/fuzz_reference.py`` (reference against the oracle, on the CPU where the
+reference checkout exists) and ``tools/fuzz_parity.py`` / ``tests/test_fuzz.py`` (HIP
+engine against the oracle, on the GPU).
+"""
+
+import numpy as np
+
+S = slice
+
+
+def _box(rs, shape, max_frac=0.6):
+    """Random non-empty box inside the grid as three slices."""
+    key = []
+    for n in shape:
+        if n == 1:
+            key.append(S(0, 1))
+            continue
+        w = int(rs.randint(1, max(2, int(n * max_frac) + 1)))
+        a = int(rs.randint(0, n - w + 1))
+        key.append(S(a, a + w))
+    return tuple(key)
+
+
+def random_scene(seed, big=False):
+    rs = np.random.RandomState(seed)
+    dims = rs.choice([1, 2, 3], p=[0.1, 0.4, 0.5])
+    lo, hi = (9, 30) if not big else (40, 90)
+    ext = [int(rs.randint(lo, hi)) for _ in range(3)]
+    flat = list(rs.permutation(3)[: 3 - dims])
+    for ax in flat:
+        ext[ax] = 1
+    if big and dims == 3:
+        ext[2] = int(rs.choice([64, 65, 96, 128, 70]))
+    shape = tuple(ext)
+    grid = dict(shape=shape)
+    if rs.rand() < 0.4:
+        grid["permittivity"] = float(1.0 + rs.rand())
+    if rs.rand() < 0.3:
+        grid["permeability"] = float(1.0 + 0.5 * rs.rand())
+
+    # ---- boundaries: per axis nothing / periodic / PML on one or both faces
+    bnd = []
+    for ax in range(3):
+        n = shape[ax]
+        full = [S(None)] * 3
+        choice = rs.choice(["none", "periodic", "pml_lo", "pml_hi", "pml_both"],
+                           p=[0.15, 0.2, 0.15, 0.15, 0.35])
+        if n == 1:
+            choice = rs.choice(["none", "periodic"])
+        if choice == "periodic":
+            key = list(full)
+            key[ax] = 0
+            bnd.append(("periodic", tuple(key), {}))
+        elif choice.startswith("pml"):
+            tmax = max(1, min(8, n // 2 - 1))
+            for side in ("lo", "hi"):
+                if choice in ("pml_" + side, "pml_both"):
+                    t = int(rs.randint(1, tmax + 1))
+                    key = list(full)
+                    key[ax] = S(0, t) if side == "lo" else S(-t, None)
+                    kw = {"a": float(10 ** rs.uniform(-9, -5))} if rs.rand() < 0.3 else {}
+                    bnd.append(("pml", tuple(key), kw))
+    order = rs.permutation(len(bnd))
+    items = [bnd[i] for i in order]
+
+    # ---- objects (may overlap each other and the PMLs)
+    n3 = [n for n in shape if n > 1]
+    for _ in range(int(rs.randint(0, 4))):
+        kind = rs.choice(["object", "absorbing", "anisotropic"])
+        key = _box(rs, shape)
+        kw = dict(permittivity=float(1.2 + 2.5 * rs.rand()))
+        extra = {}
+        if kind == "object" and rs.rand() < 0.4:
+            bs = tuple(k.stop - k.start for k in key)
+            if rs.rand() < 0.5:
+                bs = bs + (3,)      # per component; else per cell
+            kw["permittivity"] = ("randpos", int(rs.randint(1 << 30)), bs)
+        if kind == "absorbing":
+            kw["conductivity"] = float(10 ** rs.uniform(-4, 1))
+        if kind == "anisotropic" and rs.rand() < 0.7:
+            extra = dict(offdiag_seed=int(rs.randint(1 << 30)), offdiag_scale=0.05)
+        items.append((kind, key, kw, extra) if extra else (kind, key, kw))
+
+    # ---- sources
+    def cell():
+        return tuple(int(rs.randint(0, n)) for n in shape)
+
+    for _ in range(int(rs.randint(1, 4))):
+        kind = rs.choice(["point", "line", "plane"], p=[0.5, 0.3, 0.2])
+        kw = dict(period=int(rs.randint(5, 25)), amplitude=float(0.5 + rs.rand()))
+        if rs.rand() < 0.3:
+            kw["phase_shift"] = float(rs.rand())
+        if kind == "point":
+            if rs.rand() < 0.3:
+                kw.update(pulse=True, cycle=int(rs.randint(1, 4)))
+            items.append(("point", cell(), kw))
+        elif kind == "line" and len(n3) >= 1:
+            a, b = cell(), cell()
+            if max(abs(p - q) for p, q in zip(a, b)) < 2:   # at least two grid points
+                continue
+            key = tuple(S(min(p, q), max(p, q)) if p != q else p for p, q in zip(a, b))
+            if rs.rand() < 0.3:
+                kw.update(pulse=True, cycle=int(rs.randint(1, 4)))
+            items.append(("line", key, kw))
+        elif kind == "plane" and len(n3) == 3:
+            # a plane source is exactly one cell thick along exactly one axis (reference
+            # fdtd/sources.py:491-505): only true 3-D grids have room for one
+            axes = [ax for ax in range(3) if shape[ax] > 1]
+            ax = int(rs.choice(axes))
+            key = [S(None)] * 3
+            key[ax] = int(rs.randint(0, shape[ax]))
+            pol = [p for p in "xyz" if p != "xyz"[ax]]
+            kw["polarization"] = str(rs.choice(pol))
+            items.append(("plane", tuple(key), kw))
+
+    # ---- detectors
+    for _ in range(int(rs.randint(0, 3))):
+        kind = rs.choice(["linedet", "blockdet", "currentdet"])
+        if kind == "linedet":
+            a, b = cell(), cell()
+            if max(abs(p - q) for p, q in zip(a, b)) == 0:
+                continue
+            key = tuple(S(min(p, q), max(p, q)) if p != q else p for p, q in zip(a, b))
+            items.append(("linedet", key, {}))
+        elif kind == "blockdet":
+            # the reference reads the block with inclusive stops: keep one cell of margin
+            key = []
+            for n in shape:
+                if n < 3:
+                    key.append(0)
+                    continue
+                a = int(rs.randint(0, n - 2))
+                key.append(S(a, int(rs.randint(a + 1, n - 1))))
+            items.append(("blockdet", tuple(key), {}))
+        else:
+            items.append(("currentdet", cell(), {}))
+    return dict(grid=grid, items=items, steps=int(rs.randint(4, 22)))

@@ -1,0 +1,30 @@
+"""Many seeded random scenes on the HIP engine against the numpy oracle (the checker of
+tests/test_fuzz.py over a wider range of seeds):
+
+    python tools/fuzz_parity.py [first_seed] [count] [float64|float32] [big]
+
+Kernel choices can be forced from the environment (FDTDHIP_FORCE=1, FDTDHIP_FUSED=0|1).
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_fuzz  # noqa: E402
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+dtype = sys.argv[3] if len(sys.argv) > 3 else "float64"
+big = len(sys.argv) > 4 and sys.argv[4] == "big"
+bad = skipped = 0
+for seed in range(first, first + count):
+    out = test_fuzz.check_scene(seed, dtype, big=big)
+    if out is None:
+        skipped += 1
+    elif out[0]:
+        bad += 1
+        print(f"seed {seed}: {out[0]}\n   {out[1]}", flush=True)
+print(f"{dtype}{' big' if big else ''} seeds {first}..{first + count - 1}: {bad} above tolerance, "
+      f"{skipped} non-finite in the oracle (skipped)", flush=True)
+sys.exit(1 if bad else 0)
