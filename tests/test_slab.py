@@ -219,3 +219,25 @@ def test_partition_arithmetic():
         assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
     with pytest.raises(ValueError):
         Fake(3, 4, 0)
+
+
+def _fuzz(world, first, count, on_gpu, tmp_path):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_slab
+
+    seeds, bad = fuzz_slab.run(world, first, count, on_gpu, str(tmp_path / "fuzz.npz"))
+    assert len(seeds) >= count // 3
+    assert not bad, bad
+
+
+def test_random_scenes_on_slabs_cpu(tmp_path):
+    """Seeded random scenes (tests/fuzz_scenes.py) split over two ranks: the slab host logic
+    (plane ranges, ghost planes, cross-rank periodic copy, split objects and boundaries)
+    over the oracle engine must reproduce the single-grid oracle."""
+    _fuzz(2, 0, 24, False, tmp_path)
+
+
+@pytest.mark.gpu
+def test_random_scenes_on_slabs_gpu(tmp_path):
+    """The same on the HIP engine, three ranks sharing the GPU."""
+    _fuzz(3, 400, 90, True, tmp_path)
