@@ -22,6 +22,8 @@ import fuzz_scenes  # noqa: E402
 import scenes  # noqa: E402
 import slab_support  # noqa: E402
 
+BIG = os.environ.get("FUZZ_BIG") == "1"     # extents of 40-128 cells (planes for the fast kernels)
+
 
 def usable(scene, world):
     nx = scene["grid"]["shape"][0]
@@ -55,7 +57,7 @@ def worker(rank, world, port, seeds, on_gpu, out):
             factory = slab_support.OracleSlabEngine
         results = {}
         for seed in seeds:
-            scene = fuzz_scenes.random_scene(seed)
+            scene = fuzz_scenes.random_scene(seed, big=BIG)
             grid, made = scenes.build_api(
                 scene, fdtd, grid_factory=lambda **kw: SlabGrid(engine_factory=factory, **kw))
             half = scene["steps"] // 2
@@ -87,12 +89,12 @@ def oracle_fields(scene):
 
 
 def run(world, first, count, on_gpu, out):
-    seeds = [s for s in range(first, first + count) if usable(fuzz_scenes.random_scene(s), world)]
+    seeds = [s for s in range(first, first + count) if usable(fuzz_scenes.random_scene(s, big=BIG), world)]
     mp.spawn(worker, args=(world, slab_support.free_port(), seeds, on_gpu, out), nprocs=world, join=True)
     z = np.load(out)
     bad = {}
     for seed in seeds:
-        E, H = oracle_fields(fuzz_scenes.random_scene(seed))
+        E, H = oracle_fields(fuzz_scenes.random_scene(seed, big=BIG))
         for name, want in (("E", E), ("H", H)):
             got = z[f"{name}{seed}"]
             n = np.linalg.norm(want.ravel())
@@ -107,6 +109,6 @@ if __name__ == "__main__":
     on_gpu = len(sys.argv) > 4 and sys.argv[4] == "gpu"
     seeds, bad = run(world, first, count, on_gpu, f"/tmp/fuzz_slab_{os.getpid()}.npz")
     for seed, errs in bad.items():
-        print(f"seed {seed}: {errs}\n   {fuzz_scenes.random_scene(seed)}")
+        print(f"seed {seed}: {errs}\n   {fuzz_scenes.random_scene(seed, big=BIG)}")
     print(f"x{world} {'gpu' if on_gpu else 'cpu'}: {len(seeds)} scenes, {len(bad)} above 1e-12")
     sys.exit(1 if bad else 0)
