@@ -25,7 +25,7 @@ exact (bitwise) equality before it writes the fixtures that
 ``tests/test_oracle_golden.py`` replays without the reference.  Beyond those scenes,
 ``tools/fuzz_reference.py`` runs seeded random scenes (``tests/fuzz_scenes.py``: random
 shapes, boundary orders, overlapping objects, sources, detectors) through the reference and
-through this module and requires the same equality; 360 scenes, no difference.
+through this module and requires the same equality; 720 scenes, no difference.
 
 All coordinates taken here are already integers (cells / time steps given as
 ints, or seconds converted with ``steps_from_seconds``); the float-to-cell

@@ -26,7 +26,7 @@ def _box(rs, shape, max_frac=0.6):
     return tuple(key)
 
 
-def random_scene(seed, big=False):
+def random_scene(seed, big=False, extras=False):
     rs = np.random.RandomState(seed)
     dims = rs.choice([1, 2, 3], p=[0.1, 0.4, 0.5])
     lo, hi = (9, 30) if not big else (40, 90)
@@ -42,6 +42,9 @@ def random_scene(seed, big=False):
         grid["permittivity"] = float(1.0 + rs.rand())
     if rs.rand() < 0.3:
         grid["permeability"] = float(1.0 + 0.5 * rs.rand())
+
+    def cell():
+        return tuple(int(rs.randint(0, n)) for n in shape)
 
     # ---- boundaries: per axis nothing / periodic / PML on one or both faces
     bnd = []
@@ -87,9 +90,17 @@ def random_scene(seed, big=False):
         items.append((kind, key, kw, extra) if extra else (kind, key, kw))
 
     # ---- sources
-    def cell():
-        return tuple(int(rs.randint(0, n)) for n in shape)
-
+    steps = int(rs.randint(4, 22))
+    if extras and rs.rand() < 0.5:
+        # a source fed back from its own loop-current detector (reference
+        # fdtd/sources.py:708-737) and a direction-vector point source (639-700)
+        if rs.rand() < 0.6:
+            n = steps + int(rs.randint(0, 5))
+            items.append(("soft", cell(), dict(
+                waveform_array=("gauss", n, float(rs.uniform(3, n)), float(rs.uniform(3, 9)), 1e-3),
+                impedance=float(rs.choice([0.0, 0.1, 0.3])))))
+        else:
+            items.append(("ccpoint", cell(), dict(dir_vec=tuple(float(v) for v in rs.randn(3)))))
     for _ in range(int(rs.randint(1, 4))):
         kind = rs.choice(["point", "line", "plane"], p=[0.5, 0.3, 0.2])
         kw = dict(period=int(rs.randint(5, 25)), amplitude=float(0.5 + rs.rand()))
@@ -139,4 +150,4 @@ def random_scene(seed, big=False):
             items.append(("blockdet", tuple(key), {}))
         else:
             items.append(("currentdet", cell(), {}))
-    return dict(grid=grid, items=items, steps=int(rs.randint(4, 22)))
+    return dict(grid=grid, items=items, steps=steps)

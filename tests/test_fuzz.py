@@ -1,7 +1,7 @@
 """Seeded random scenes (tests/fuzz_scenes.py) on the HIP engine against the numpy oracle.
 
 The same generator, run through the real reference where its checkout exists
-(tools/fuzz_reference.py), showed the oracle bitwise equal to the reference on 300 scenes;
+(tools/fuzz_reference.py), showed the oracle bitwise equal to the reference on 720 scenes;
 here the engine has to match the oracle on a spread of them: float64 to 1e-12, float32 to
 1e-5 (relative L2 of E, H and every detector trace; the live PML memory variables
 to 1e-12 in float64 only, loop currents to 1e-3 in float32).
@@ -51,9 +51,9 @@ def live_psi(ot):
                      ot.psi_H[u][..., ot.axis], ot.psi_H[v][..., ot.axis]])
 
 
-def check_scene(seed, dtype, big=False):
+def check_scene(seed, dtype, big=False, extras=False):
     fdtd.set_backend(f"hip.{dtype}")
-    scene = fuzz_scenes.random_scene(seed, big=big)
+    scene = fuzz_scenes.random_scene(seed, big=big, extras=extras)
     grid, made = scenes.build_api(scene, fdtd)
     resolved, arrays = scenes.resolve(scene, grid, made)
     ogrid, omade = scenes.build_oracle(resolved, arrays)
@@ -72,6 +72,10 @@ def check_scene(seed, dtype, big=False):
             errs[f"det{n}_H"] = rel_l2(host(t.H), np.array(ot.H))
         elif kind == "currentdet":
             errs[f"det{n}_I"] = rel_l2(host(t.I), np.array(ot.I))
+        elif kind == "soft":   # both voltage records and the loop current that feeds back
+            errs[f"src{n}_vin"] = rel_l2(host(t.input_voltage), np.array(ot.input_voltage, dtype=np.float64))
+            errs[f"src{n}_vout"] = rel_l2(host(t.source_voltage), np.array(ot.source_voltage, dtype=np.float64))
+            errs[f"src{n}_I"] = rel_l2(host(t.current_detector.I), np.array(ot.current_detector.I))
     if dtype == "float32":
         errs = {k: v for k, v in errs.items() if not k.startswith("psi")}
     return {k: v for k, v in errs.items()
@@ -86,6 +90,17 @@ def test_random_scenes_match_oracle(dtype, seeds):
         if out and out[0]:
             bad[seed] = out
     assert not bad, f"{dtype}: scenes above {TOL[dtype]}: {bad}"
+
+
+def test_random_scenes_with_feedback_sources_match_oracle():
+    """The same with a source fed back from its loop-current detector or a direction-vector
+    point source in about half of the scenes."""
+    bad = {}
+    for seed in range(100, 160):
+        out = check_scene(seed, "float64", extras=True)
+        if out and out[0]:
+            bad[seed] = out
+    assert not bad, f"scenes above 1e-12: {bad}"
 
 
 def test_random_larger_scenes_match_oracle():

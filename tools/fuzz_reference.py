@@ -22,6 +22,8 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 sys.path.insert(0, sys.argv[3] if len(sys.argv) > 3 else "/root/reference")
 os.environ.setdefault("MPLBACKEND", "Agg")
 
+EXTRAS = os.environ.get("FUZZ_EXTRAS") == "1"   # soft and direction-vector point sources too
+
 import fdtd as ref  # noqa: E402  (the real reference)
 
 import fuzz_scenes  # noqa: E402
@@ -42,7 +44,7 @@ def same(a, b, what):
 
 
 def one(seed):
-    scene = fuzz_scenes.random_scene(seed)
+    scene = fuzz_scenes.random_scene(seed, extras=EXTRAS)
     ref.set_backend("numpy")
     with contextlib.redirect_stdout(io.StringIO()):
         rgrid, rmade = scenes.build_api(scene, ref)
@@ -65,6 +67,11 @@ def one(seed):
                 same(np.array(getattr(ot, f)), np.array(getattr(rt, f)), f"detector {n} {f}")
         elif kind == "currentdet":
             same(np.array(ot.I), np.array(rt.I), f"detector {n} I")
+        elif kind == "soft":
+            for attr in ("input_voltage", "source_voltage"):
+                same(np.array(getattr(ot, attr), dtype=np.float64),
+                     np.array(getattr(rt, attr), dtype=np.float64), f"source {n} {attr}")
+            same(np.array(ot.current_detector.I), np.array(rt.current_detector.I), f"source {n} loop current")
     return scene, bool(np.isfinite(rgrid.E).all())
 
 
@@ -76,7 +83,7 @@ for seed in range(first, first + count):
             print(f"seed {seed}: non-finite fields (still equal)")
     except Differs as e:
         bad += 1
-        print(f"seed {seed}: ORACLE DIFFERS FROM REFERENCE: {e}\n   {fuzz_scenes.random_scene(seed)}")
+        print(f"seed {seed}: ORACLE DIFFERS FROM REFERENCE: {e}\n   {fuzz_scenes.random_scene(seed, extras=EXTRAS)}")
     except Exception:  # noqa: BLE001 -- a scene the reference itself refuses is a generator bug
         skipped += 1
         print(f"seed {seed}: construction/run error\n{traceback.format_exc(limit=3)}")
