@@ -76,9 +76,9 @@ class _Detector:
             for v, n in ((x, g.Nx_global), (y, g.Ny), (z, g.Nz)):
                 if not -n <= v < n:
                     raise IndexError(f"index {v} is out of bounds for axis with size {n}")
-            xl = g._local_x(x % g.Nx_global)
+            xl = g._local_x(g._cell_index(x, g.Nx_global))
             if xl is not None:
-                out.append((xl, y % g.Ny, z % g.Nz))
+                out.append((xl, g._cell_index(y, g.Ny), g._cell_index(z, g.Nz)))
         return out
 
     def _native_add(self, lib, plan):
@@ -165,7 +165,7 @@ class BlockDetector(LineDetector):
 
     def _local_x_count(self):
         g = self.grid
-        return sum(1 for x in self.x if g._local_x(x % g.Nx_global) is not None)
+        return sum(1 for x in self.x if g._local_x(g._cell_index(x, g.Nx_global)) is not None)
 
     def _shape(self):
         return (self._local_x_count(), len(self.y), len(self.z), 3)
@@ -191,7 +191,7 @@ class CurrentDetector(_Detector):
     def _reserve(self, lib, plan, nE, nH):
         if self._bufH is None:
             g = self.grid
-            nxl = sum(1 for x in self.x if g._local_x(x % g.Nx_global) is not None)
+            nxl = sum(1 for x in self.x if g._local_x(g._cell_index(x, g.Nx_global)) is not None)
             self._bufH = _Readings((nxl, len(self.y), len(self.z)))
         pH = self._bufH.reserve(nH)
         _lib.check(lib.fdtdhip_plan_set_detector_output(

@@ -189,6 +189,15 @@ class Grid:
             z=self._handle_single_key(z),
         )
 
+    @staticmethod
+    def _cell_index(v, n):
+        """Python-style index into an axis of ``n`` cells: negative values count from the
+        end, anything beyond raises the IndexError that numpy raises in the reference's
+        first step (e.g. fdtd/sources.py:111 with a source outside the grid)."""
+        if not -n <= v < n:
+            raise IndexError(f"index {v} is out of bounds for axis with size {n}")
+        return v % n
+
     def _claim_name(self, thing):
         """``grid.<name>`` access to named components (e.g. reference fdtd/boundaries.py:54-60)."""
         if thing.name is None:

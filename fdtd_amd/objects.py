@@ -30,12 +30,21 @@ class Object:
         self.permittivity = permittivity
 
     def _register_grid(self, grid: Grid, x: ListOrSlice, y: ListOrSlice, z: ListOrSlice):
-        self.grid = grid
-        grid.objects.append(self)
-        grid._claim_name(self)
+        if self.name is not None and hasattr(grid, self.name):   # as _claim_name, before anything else
+            raise ValueError(f"The grid already has an attribute with name {self.name}")
         # x in the coordinates of the whole simulation, then the part this grid owns
         # (everything, unless the grid is one x-slab of a decomposed simulation)
         self.x_global = self._handle_slice(x, max_index=grid.Nx_global)
+        yz = (self._handle_slice(y, max_index=grid.Ny), self._handle_slice(z, max_index=grid.Nz))
+        for s, n in zip((self.x_global,) + yz, (grid.Nx_global, grid.Ny, grid.Nz)):
+            # The reference registers such a box and then fails in its first update_E, when
+            # the box-sized tensor meets the clipped field slice (fdtd/objects.py:116-126);
+            # refused here, where the mistake is made.
+            if s.start < 0 or s.stop > n or s.stop < s.start:
+                raise IndexError(f"object box {s.start}:{s.stop} outside the grid (0:{n})")
+        self.grid = grid
+        grid.objects.append(self)
+        grid._claim_name(self)
         lo, hi = grid._clip_x(self.x_global.start, self.x_global.stop)
         self.x = slice(lo, hi, None)
         self.y = self._handle_slice(y, max_index=grid.Ny)

@@ -96,10 +96,10 @@ class PointSource(_Waveform):
 
     def _native_add(self, lib, plan):
         g = self.grid
-        xl = g._local_x(self.x % g.Nx_global)  # negative indices wrap like Python
+        xl = g._local_x(g._cell_index(self.x, g.Nx_global))  # negative indices wrap like Python
         if xl is None:  # the cell belongs to another x-slab
             return
-        cell = [xl, self.y % g.Ny, self.z % g.Nz]
+        cell = [xl, g._cell_index(self.y, g.Ny), g._cell_index(self.z, g.Nz)]
         _lib.check(lib.fdtdhip_plan_add_source(
             plan, _lib.SRC_ADD_POINTS, 2, 2, 1, _lib.int32s(cell),
             _lib.doubles([self.amplitude]), *self._wave_args()))
@@ -139,9 +139,9 @@ class CorticalColumnPointSource(PointSource):
         weights = [-d[0], d[0], -d[1], d[1], -d[2], d[2]]
         flat, prof = [], []
         for (x, y, z), w in zip(cells, weights):
-            xl = g._local_x(x % g.Nx_global)
+            xl = g._local_x(g._cell_index(x, g.Nx_global))
             if xl is not None:
-                flat += [xl, y % g.Ny, z % g.Nz]
+                flat += [xl, g._cell_index(y, g.Ny), g._cell_index(z, g.Nz)]
                 prof.append(self.amplitude * w)
         if prof:
             _lib.check(lib.fdtdhip_plan_add_source(
@@ -196,9 +196,9 @@ class LineSource(_Waveform):
         g = self.grid
         cells, profile = [], []
         for x, y, z, p in zip(self.x, self.y, self.z, self.profile):
-            xl = g._local_x(x % g.Nx_global)
+            xl = g._local_x(g._cell_index(x, g.Nx_global))
             if xl is not None:  # points of other x-slabs are injected there
-                cells += [xl, y % g.Ny, z % g.Nz]
+                cells += [xl, g._cell_index(y, g.Ny), g._cell_index(z, g.Nz)]
                 profile.append(p)
         if not profile:
             return
@@ -458,7 +458,7 @@ class SoftArbitraryPointSource:
         w = np.ascontiguousarray(
             bd.numpy(self.waveform_array) if torch.is_tensor(self.waveform_array)
             else self.waveform_array, dtype=np.float64).reshape(-1)
-        cell = [self.x % g.Nx, self.y % g.Ny, self.z % g.Nz]
+        cell = [g._cell_index(self.x, g.Nx), g._cell_index(self.y, g.Ny), g._cell_index(self.z, g.Nz)]
         self._native_id = _lib.check(lib.fdtdhip_plan_add_soft_source(
             plan, _lib.int32s(cell), w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), w.size,
             float(self.impedance), float(g.grid_spacing)))

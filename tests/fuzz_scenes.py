@@ -26,7 +26,7 @@ def _box(rs, shape, max_frac=0.6):
     return tuple(key)
 
 
-def random_scene(seed, big=False, extras=False):
+def random_scene(seed, big=False, extras=False, floats=False):
     rs = np.random.RandomState(seed)
     dims = rs.choice([1, 2, 3], p=[0.1, 0.4, 0.5])
     lo, hi = (9, 30) if not big else (40, 90)
@@ -150,4 +150,30 @@ def random_scene(seed, big=False, extras=False):
             items.append(("blockdet", tuple(key), {}))
         else:
             items.append(("currentdet", cell(), {}))
-    return dict(grid=grid, items=items, steps=steps)
+    scene = dict(grid=grid, items=items, steps=steps)
+    return with_float_keys(scene, rs) if floats else scene
+
+
+def with_float_keys(scene, rs, spacing=155e-9):
+    """The same scene with some coordinates given in metres (floats), as users of the API
+    write them (reference fdtd/grid.py:171-210): grid extents, object / source / detector
+    positions and slice ends, source periods in seconds."""
+    def f(c, lo=-0.45, hi=0.45):
+        return float((c + rs.uniform(lo, hi)) * spacing)
+
+    shape = tuple(f(n) if n > 1 and rs.rand() < 0.3 else n for n in scene["grid"]["shape"])
+    items = []
+    for item in scene["items"]:
+        kind, key, kw = item[0], item[1], dict(item[2])
+        if kind not in ("pml", "periodic") and rs.rand() < 0.6:
+            new = []
+            for k in key:
+                if isinstance(k, slice) and k.start is not None and k.stop is not None and rs.rand() < 0.7:
+                    new.append(slice(f(k.start), f(k.stop)) if k.stop > k.start + 0 else k)
+                elif isinstance(k, int) and not isinstance(k, bool) and rs.rand() < 0.7:
+                    new.append(f(k, 0.0, 0.45) if k == 0 else f(k))
+                else:
+                    new.append(k)
+            key = tuple(new)
+        items.append((kind, key, kw) + tuple(item[3:]))
+    return dict(grid=dict(scene["grid"], shape=shape), items=items, steps=scene["steps"])

@@ -250,3 +250,25 @@ def test_backend_precision_switch_between_runs():
     fdtd.set_backend("hip.float64")
     g.run(5, progress_bar=False); o.run(5)
     assert g.E.dtype == torch.float64 and rel_l2(host(g.H), o.H) <= 1e-5
+
+
+def test_cells_outside_the_grid_raise_at_the_first_step():
+    """A source or detector cell beyond the grid is accepted at registration and raises
+    IndexError in the first step, as numpy does for the reference (fdtd/sources.py:111,
+    fdtd/detectors.py:117); negative indices count from the end."""
+    fdtd.set_backend("hip.float64")
+    for bad in ("source", "detector"):
+        g = fdtd.Grid((8, 7, 6))
+        if bad == "source":
+            g[10, 0, 0] = fdtd.PointSource(period=9)
+        else:
+            g[8, 3, 3] = fdtd.BlockDetector()
+        with pytest.raises(IndexError):
+            g.run(1, progress_bar=False)
+    g, o = fdtd.Grid((8, 7, 6)), orc.OracleGrid((8, 7, 6))
+    g[-1, -2, -3] = fdtd.PointSource(period=9)
+    o.add_point_source((7, 5, 3), period=9)
+    g.run(6, progress_bar=False)
+    o.run(6)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(g.E), o.E) and np.array_equal(host(g.H), o.H)
