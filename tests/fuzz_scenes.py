@@ -162,9 +162,13 @@ def with_float_keys(scene, rs, spacing=155e-9):
         return float((c + rs.uniform(lo, hi)) * spacing)
 
     shape = tuple(f(n) if n > 1 and rs.rand() < 0.3 else n for n in scene["grid"]["shape"])
+    dims = max(1, sum(1 for n in scene["grid"]["shape"] if n > 1))
+    time_step = 0.99 * dims ** -0.5 * spacing / 299792458.0   # reference fdtd/grid.py:119-132
     items = []
     for item in scene["items"]:
         kind, key, kw = item[0], item[1], dict(item[2])
+        if isinstance(kw.get("period"), int) and rs.rand() < 0.3:
+            kw["period"] = float((kw["period"] + rs.uniform(-0.3, 0.3)) * time_step)
         if kind not in ("pml", "periodic") and rs.rand() < 0.6:
             new = []
             for k in key:

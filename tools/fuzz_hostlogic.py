@@ -6,8 +6,9 @@ host-staging device):
     python tools/fuzz_hostlogic.py [first_seed] [count] [/root/reference]
 
 For every scene both sides must resolve every component to the same integer cells (boxes,
-point lists, PML faces and thicknesses, polarisations), build the same object tensors and
-leave the same inverse permittivity on the grid -- or raise the same exception type.
+point lists, PML faces and thicknesses, polarisations, periods in steps), build the same
+object tensors, leave the same inverse permittivity on the grid and print the same
+``str(grid)`` -- or raise the same exception type.
 """
 import contextlib
 import io
@@ -62,7 +63,7 @@ def build(mod, scene):
         if kind in ("object", "absorbing", "anisotropic"):
             m = t.inverse_permittivity
             objs.append(m if isinstance(m, np.ndarray) else m.detach().cpu().numpy())
-    return None, resolved, (inv, objs), float(grid.time_step)
+    return None, resolved, (inv, objs), (float(grid.time_step), str(grid), [repr(t) for _, t, _, _ in made])
 
 
 S = slice
@@ -110,7 +111,7 @@ for seed in range(first, first + count):
     elif scenes.dumps(rres) != scenes.dumps(ares):
         what = f"resolved coordinates differ:\n  ref {scenes.dumps(rres)}\n  amd {scenes.dumps(ares)}"
     elif rdt != adt:
-        what = f"time step differs: {rdt} {adt}"
+        what = f"time step or printed form differs:\n  ref {rdt}\n  amd {adt}"
     elif not np.array_equal(rarr[0], aarr[0]) or any(
             not np.array_equal(a, b) for a, b in zip(rarr[1], aarr[1])):
         what = "material arrays differ"
