@@ -21,7 +21,9 @@ def _series(readings):
 
 def _pad_edge(x, n):
     """``n`` copies of the last sample appended (numpy.pad mode 'edge', reference fourier.py:204)."""
-    if n <= 0 or x.numel() == 0:
+    if n < 0:   # numpy.pad refuses it: a bin resolution alone gives a negative bin count
+        raise ValueError("index can't contain negative values")
+    if n == 0 or x.numel() == 0:
         return x
     return torch.cat([x, x[-1:].expand(n)])
 
