@@ -109,6 +109,8 @@ def random_scene(seed, big=False, extras=False, floats=False):
         if kind == "point":
             if rs.rand() < 0.3:
                 kw.update(pulse=True, cycle=int(rs.randint(1, 4)))
+                if rs.rand() < 0.5:
+                    kw["hanning_dt"] = float(rs.uniform(2.0, 12.0))
             items.append(("point", cell(), kw))
         elif kind == "line" and len(n3) >= 1:
             a, b = cell(), cell()
@@ -117,6 +119,8 @@ def random_scene(seed, big=False, extras=False, floats=False):
             key = tuple(S(min(p, q), max(p, q)) if p != q else p for p, q in zip(a, b))
             if rs.rand() < 0.3:
                 kw.update(pulse=True, cycle=int(rs.randint(1, 4)))
+                if rs.rand() < 0.5:
+                    kw["hanning_dt"] = float(rs.uniform(2.0, 12.0))
             items.append(("line", key, kw))
         elif kind == "plane" and len(n3) == 3:
             # a plane source is exactly one cell thick along exactly one axis (reference
