@@ -8,6 +8,7 @@ nothing of the time stepping is computed in Python or by torch operators.
 """
 
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -323,11 +324,14 @@ class Grid:
         next half step; arrays that keep changing are scanned a few times and then
         simply read by the kernels.  Writes that bypass the counter (``tensor.data``,
         foreign code holding the pointer) must be followed by ``materials_changed()``."""
+        # (the tensors themselves are part of the key, held weakly: a re-bound array can land
+        # on the address of the one it replaced, with the same version count)
         key = (ie.data_ptr(), ie._version, im.data_ptr(), im._version)
         last = getattr(self, "_materials_key", None)
-        if key == last:
+        same = last is not None and last[0] == key and last[1]() is ie and last[2]() is im
+        if same:
             return
-        self._materials_key = key
+        self._materials_key = (key, weakref.ref(ie), weakref.ref(im))
         scans = getattr(self, "_material_scans", 0)
         if last is not None:  # the arrays changed under an unchanged plan
             self._material_scans = scans = scans + 1

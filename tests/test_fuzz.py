@@ -175,3 +175,110 @@ def test_random_scenes_adjoint_against_finite_differences():
         if not err <= 1e-5:
             bad[seed] = (err, analytic, numeric, scene)
     assert not bad, bad
+
+
+def operation_sequence_mismatch(seed):
+    """A random scene driven by a random sequence of user operations between runs -- writes
+    into the material arrays (in place and by re-binding), into the fields, into an object's
+    tensor, components registered after steps were taken, runs through ``run`` and through
+    the half-step entry points -- mirrored on the oracle.  Exercises everything the host
+    layer caches between runs (plan signature, bound pointers, constant-material scan)."""
+    from oracle import yee_numpy as orc  # noqa: F401  (the oracle is the checker here)
+
+    fdtd.set_backend("hip.float64")
+    rs = np.random.RandomState(seed)
+    scene = fuzz_scenes.random_scene(seed)
+    grid, made = scenes.build_api(scene, fdtd)
+    resolved, arrays = scenes.resolve(scene, grid, made)
+    og, omade = scenes.build_oracle(resolved, arrays)
+    shape = (grid.Nx, grid.Ny, grid.Nz)
+    objs = [(t, ot) for (k, t, _, _), (_, ot) in zip(made, omade) if k in ("object", "absorbing", "anisotropic")]
+    log = []
+
+    def box():
+        return tuple(slice(a.start, a.stop) for a in fuzz_scenes._box(rs, shape))
+
+    for _ in range(int(rs.randint(4, 10))):
+        op = rs.choice(["run", "halfsteps", "eps_inplace", "mu_inplace", "eps_rebind", "field", "object",
+                        "add_source", "add_detector", "add_object", "reset"])
+        log.append(str(op))
+        if op == "run":
+            n = int(rs.randint(1, 7))
+            grid.run(n, progress_bar=False)
+            og.run(n)
+        elif op == "halfsteps":
+            for _ in range(int(rs.randint(1, 4))):
+                grid.update_E(); og.update_E()
+                grid.update_H(); og.update_H()
+                grid.time_steps_passed += 1
+                og.time_steps_passed += 1
+        elif op in ("eps_inplace", "mu_inplace"):
+            b = box()
+            name = "inverse_permittivity" if op == "eps_inplace" else "inverse_permeability"
+            vals = 0.3 + 0.7 * rs.rand(*[s.stop - s.start for s in b], 3)
+            getattr(grid, name)[b] = fdtd.backend.array(vals)
+            getattr(og, name)[b] = vals
+        elif op == "eps_rebind":
+            vals = 0.3 + 0.7 * rs.rand(*shape, 3)
+            grid.inverse_permittivity = fdtd.backend.array(vals)
+            og.inverse_permittivity = vals.copy()
+        elif op == "field":
+            b = box()
+            name = str(rs.choice(["E", "H"]))
+            vals = 1e-2 * rs.randn(*[s.stop - s.start for s in b], 3)
+            with torch.no_grad():
+                getattr(grid, name)[b] = fdtd.backend.array(vals)
+            getattr(og, name)[b] = vals
+        elif op == "object" and objs:
+            t, ot = objs[int(rs.randint(len(objs)))]
+            f = float(0.5 + rs.rand())
+            with torch.no_grad():
+                t.inverse_permittivity *= f
+            ot.inverse_permittivity *= f
+        elif op == "add_source":
+            c = tuple(int(rs.randint(0, n)) for n in shape)
+            p = int(rs.randint(5, 20))
+            grid[c] = fdtd.PointSource(period=p)
+            og.add_point_source(c, period=p)
+        elif op == "add_detector":
+            c = tuple(int(rs.randint(0, n)) for n in shape)
+            d = fdtd.BlockDetector()
+            grid[c[0]:c[0] + 1, c[1]:c[1] + 1, c[2]:c[2] + 1] = d
+            # the reference reads a block with inclusive stops: keep it inside the grid
+            if all(ci + 1 < n or n == 1 for ci, n in zip(c, shape)) and min(shape) > 1:
+                od = og.add_block_detector([c[0], c[0] + 1], [c[1], c[1] + 1], [c[2], c[2] + 1])
+                made.append(("blockdet_late", d, od, None))
+            else:
+                grid.detectors.remove(d)
+        elif op == "reset":
+            # fields and step counter only; memory variables and detector records stay
+            # (reference fdtd/grid.py:327-333)
+            grid.reset()
+            og.E[...] = 0.0
+            og.H[...] = 0.0
+            og.time_steps_passed = 0
+        elif op == "add_object":
+            b = box()
+            eps = float(1.5 + rs.rand())
+            grid[b] = fdtd.Object(permittivity=eps)
+            og.add_object([b[0].start, b[0].stop, b[1].start, b[1].stop, b[2].start, b[2].stop], eps, kind="object")
+    grid.run(2, progress_bar=False)
+    og.run(2)
+    torch.cuda.synchronize()
+    if not np.isfinite(og.E).all():
+        return None
+    errs = {"E": rel_l2(host(grid.E), og.E), "H": rel_l2(host(grid.H), og.H),
+            "inv_eps": rel_l2(host(grid.inverse_permittivity), og.inverse_permittivity)}
+    for n, item in enumerate(made):
+        if item[0] == "blockdet_late" and len(item[2].E):
+            errs[f"late{n}"] = rel_l2(host(item[1].E), np.array(item[2].E))
+    return {k: v for k, v in errs.items() if not v <= 1e-12}, log
+
+
+def test_random_operation_sequences_match_oracle():
+    bad = {}
+    for seed in range(500, 560):
+        out = operation_sequence_mismatch(seed)
+        if out and out[0]:
+            bad[seed] = out
+    assert not bad, bad
