@@ -282,3 +282,67 @@ def test_random_operation_sequences_match_oracle():
         if out and out[0]:
             bad[seed] = out
     assert not bad, bad
+
+
+def training_loop_mismatch(seed):
+    """A grid re-used over optimisation iterations (reset, differentiable run of varying
+    length, backward, in-place parameter update, sometimes a no-grad run in between) against
+    a freshly built grid per iteration: losses and gradients must be bitwise equal.  Scenes
+    without PML, whose memory variables ``reset()`` keeps (reference fdtd/grid.py:327-333)."""
+    fdtd.set_backend("hip.float64")
+    rs = np.random.RandomState(seed + 4242)
+    scene = fuzz_scenes.random_scene(seed)
+    scene["items"] = [it for it in scene["items"] if it[0] != "pml"]
+    shape = scene["grid"]["shape"]
+    box = fuzz_scenes._box(rs, shape, max_frac=0.5)
+    scene["items"].append(("learnable", box, dict(permittivity=float(1.5 + rs.rand())),
+                           dict(offdiag_seed=int(rs.randint(1 << 30)), offdiag_scale=0.03)))
+    if not any(it[0] in ("point", "line", "plane") for it in scene["items"]):
+        scene["items"].append(("point", tuple(n // 2 for n in shape), dict(period=9)))
+
+    def learnable(made):
+        return [t for k, t, _, _ in made if k == "learnable"][0]
+
+    def loss_of(grid):
+        w = np.random.RandomState(seed + 5)
+        WE, WH = fdtd.backend.array(w.rand(*grid.E.shape)), fdtd.backend.array(w.rand(*grid.E.shape))
+        return (WE * grid.E ** 2).sum() + (WH * grid.H ** 2).sum()
+
+    grid, made = scenes.build_api(scene, fdtd)
+    obj = learnable(made)
+    bad = {}
+    for it in range(int(rs.randint(2, 5))):
+        n = int(rs.randint(2, 14))
+        if rs.rand() < 0.3:
+            with torch.no_grad():
+                grid.run(int(rs.randint(1, 5)), progress_bar=False)
+        grid.reset()
+        grid.run(n, progress_bar=False)
+        loss = loss_of(grid)
+        loss.backward()
+        # the same iteration on a fresh grid with the same parameter values
+        fresh, fmade = scenes.build_api(scene, fdtd)
+        fobj = learnable(fmade)
+        with torch.no_grad():
+            fobj.inverse_permittivity.copy_(obj.inverse_permittivity)
+        fresh.run(n, progress_bar=False)
+        floss = loss_of(fresh)
+        floss.backward()
+        if loss.item() != floss.item():
+            bad[f"loss{it}"] = (loss.item(), floss.item())
+        if not torch.equal(obj.inverse_permittivity.grad, fobj.inverse_permittivity.grad):
+            bad[f"grad{it}"] = float((obj.inverse_permittivity.grad - fobj.inverse_permittivity.grad).abs().max())
+        with torch.no_grad():
+            obj.inverse_permittivity -= 0.05 * obj.inverse_permittivity.grad / (
+                obj.inverse_permittivity.grad.abs().max() + 1e-30)
+            obj.inverse_permittivity.grad = None
+    return bad
+
+
+def test_reused_grid_training_loop_equals_fresh_grids():
+    bad = {}
+    for seed in range(900, 930):
+        out = training_loop_mismatch(seed)
+        if out:
+            bad[seed] = out
+    assert not bad, bad
