@@ -227,11 +227,31 @@ class SlabGrid(Grid):
             return
         from . import autograd
 
-        if not bd.staging and autograd.needs_grad(self):
+        if not bd.staging and self._any_rank_needs_grad():
             autograd.differentiable_advance(self, n)
             return
         self._native_run(None, n)
         self.time_steps_passed += n
+
+    def _any_rank_needs_grad(self):
+        """Whether this run has to be recorded for a backward pass.  Collective when gradients
+        are enabled: the reverse sweep exchanges planes between neighbours, so either every
+        rank records the run or none does -- also a rank that holds no cell of any learnable
+        object.  Such a rank ties the run to its E field, whose adjoint the sweep needs anyway."""
+        from . import autograd
+
+        if not torch.is_grad_enabled():
+            return False
+        mine = autograd.needs_grad(self)
+        if self._world == 1:
+            return mine
+        on_device = self._backend_name == "nccl"
+        flag = torch.tensor([1 if mine else 0], device=bd.device if on_device else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self._group)
+        wanted = bool(flag.item())
+        if wanted and not mine:
+            self.E = self.E.detach().requires_grad_(True)
+        return wanted
 
     def _native_run(self, lib, n):
         eng = self._engine

@@ -241,3 +241,16 @@ def test_random_scenes_on_slabs_cpu(tmp_path):
 def test_random_scenes_on_slabs_gpu(tmp_path):
     """The same on the HIP engine, three ranks sharing the GPU."""
     _fuzz(3, 400, 90, True, tmp_path)
+
+
+@pytest.mark.gpu
+def test_random_scenes_slab_gradients_gpu(tmp_path):
+    """Differentiable runs of random scenes on three slabs -- the learnable object anywhere,
+    also on one slab only, so that some ranks record the run for their neighbours' sake --
+    against the same engine on the undivided grid."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_slab_adjoint
+
+    seeds, bad = fuzz_slab_adjoint.run(3, 100, 90, str(tmp_path / "adj.npz"))
+    assert len(seeds) >= 20
+    assert not bad, bad
