@@ -130,6 +130,12 @@ def half_step_bytes(grid, cells, es, mask):
     return e, h
 
 
+def torch_no_grad():
+    import torch
+
+    return torch.no_grad()
+
+
 def timed_run(grid, lib, _lib, steps, sync, events=True):
     """Time `steps` steps; returns (seconds, ms in E kernels, launches, ms in H kernels, launches).
     events=False leaves out the HIP events around every bulk launch (they cost a launch-bound
@@ -138,7 +144,8 @@ def timed_run(grid, lib, _lib, steps, sync, events=True):
     _lib.check(lib.fdtdhip_plan_enable_timing(plan, 1 if events else 0))
     sync()
     t0 = time.perf_counter()
-    grid.run(steps, progress_bar=False)
+    with torch_no_grad():     # plain time stepping: nothing to record, no collective about it
+        grid.run(steps, progress_bar=False)
     sync()
     elapsed = time.perf_counter() - t0
     msE, nE, msH, nH = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
@@ -297,7 +304,8 @@ def main():
 
     if args.materials == "arrays":
         use_material_arrays(grid, lib, _lib)
-    grid.run(args.warmup, progress_bar=False)
+    with torch_no_grad():
+        grid.run(args.warmup, progress_bar=False)
     sync()
     mask = 0 if args.materials == "arrays" else _lib.check(lib.fdtdhip_plan_scan_materials(grid._plan, 1))
     if args.workload == "c1":
@@ -332,7 +340,8 @@ def main():
     if mask and world == 1 and args.also_arrays:
         # the same grid with every kernel reading both material arrays
         use_material_arrays(grid, lib, _lib)
-        grid.run(args.warmup, progress_bar=False)
+        with torch_no_grad():
+            grid.run(args.warmup, progress_bar=False)
         sync()
         el2, e2, _, h2, _ = timed_run(grid, lib, _lib, args.steps, sync)
         r2 = roofline(e2, h2, 0, args.steps)
