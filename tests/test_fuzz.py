@@ -346,3 +346,4 @@ def test_reused_grid_training_loop_equals_fresh_grids():
         if out:
             bad[seed] = out
     assert not bad, bad
+
