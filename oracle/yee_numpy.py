@@ -212,8 +212,13 @@ class OraclePeriodic:
 # objects
 # ----------------------------------------------------------------------------
 class OracleObject:
-    """Dielectric box.  ``kind``: 'object' | 'absorbing' | 'anisotropic'
-    (reference fdtd/objects.py:60-90, 116-126, 188-218, 244-266)."""
+    """Dielectric box.  ``kind``: 'object' | 'absorbing' | 'anisotropic' | 'substrate'
+    (reference fdtd/objects.py:60-90, 116-126, 188-218, 244-266; 'substrate' is the
+    LearnableAnisotropicObject with is_substrate=True of 276-349: an anisotropic tensor whose
+    nine entries are scaled, per cell and step, by sigmoid(w_E*sum(E^2) + w_H*sum(H^2) + b);
+    ``modifier_weights`` holds (w_E, w_H, b) per entry, shape (9, 3), set by the caller.
+    The reference's reshape of the 1x1 convolution's output (334-337) only works for boxes
+    one cell thick along z)."""
 
     def __init__(self, grid, kind, box, permittivity, conductivity=None):
         x0, x1, y0, y1, z0, z1 = box
@@ -242,7 +247,11 @@ class OracleObject:
             self.absorption_factor = (
                 0.5 * grid.courant_number * inv * cond * grid.grid_spacing * ETA0
             )
-        elif kind == "anisotropic":
+        elif kind in ("anisotropic", "substrate"):
+            if kind == "substrate":
+                if self.Nz != 1:
+                    raise ValueError("a substrate object has to be one cell thick along z")
+                self.modifier_weights = np.zeros((9, 3))
             eye = np.zeros((self.Nx * self.Ny * self.Nz, 3, 3))
             eye[:, range(3), range(3)] = 1.0
             self.inverse_permittivity = np.reshape(
@@ -261,9 +270,21 @@ class OracleObject:
             g.E[loc] *= (1 - f) / (1 + f)
             g.E[loc] += sc * self.inverse_permittivity * curl[loc] / (1 + f)
         else:
+            tensor = self.inverse_permittivity
+            if self.kind == "substrate":
+                # energies of the fields as they are now: E after the grid's own update and
+                # the objects registered earlier (reference fdtd/objects.py:328-337)
+                eE = np.sum(g.E[loc] ** 2, -1)
+                eH = np.sum(g.H[loc] ** 2, -1)
+                w = self.modifier_weights
+                z = w[:, 0][None, None, None, :] * eE[..., None] + w[:, 1][None, None, None, :] * eH[..., None] \
+                    + w[:, 2][None, None, None, :]
+                with np.errstate(over="ignore"):     # exp(+big) = inf gives the limit 0
+                    mod = 1.0 / (1.0 + np.exp(-z))
+                tensor = tensor * np.reshape(mod, (self.Nx, self.Ny, self.Nz, 3, 3))
             prod = np.einsum(
                 "ijk,ikl->ijl",
-                np.reshape(self.inverse_permittivity, (-1, 3, 3)),
+                np.reshape(tensor, (-1, 3, 3)),
                 np.reshape(curl[loc], (-1, 3, 1)),
             )
             g.E[loc] += np.reshape(sc * prod, (self.Nx, self.Ny, self.Nz, 3))

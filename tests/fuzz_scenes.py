@@ -185,3 +185,21 @@ def with_float_keys(scene, rs, spacing=155e-9):
             key = tuple(new)
         items.append((kind, key, kw) + tuple(item[3:]))
     return dict(grid=dict(scene["grid"], shape=shape), items=items, steps=scene["steps"])
+
+
+def random_substrate_scene(seed):
+    """A random 2-D scene (z extent 1) with an energy-modulated substrate object
+    (LearnableAnisotropicObject(is_substrate=True), reference fdtd/objects.py:276-349) added:
+    the reference's modifier only works for boxes one cell thick along z."""
+    for k in range(200):
+        scene = random_scene(seed * 200 + k)
+        nx, ny, nz = scene["grid"]["shape"]
+        if nz == 1 and nx > 3 and ny > 3:
+            break
+    rs = np.random.RandomState(seed + 31337)
+    box = _box(rs, (nx, ny, 1), max_frac=0.8)
+    scene["items"].insert(int(rs.randint(len(scene["items"]) + 1)), (
+        "substrate", (box[0], box[1], S(None)), dict(permittivity=float(1.3 + 2.0 * rs.rand())),
+        dict(offdiag_seed=int(rs.randint(1 << 30)), offdiag_scale=0.04,
+             conv_seed=int(rs.randint(1 << 30)), conv_scale=float(10 ** rs.uniform(0, 2.5)))))
+    return scene

@@ -562,7 +562,7 @@ def resolve(scene, grid, made):
             out["items"].append(dict(kind=kind, axis=axis, side=side, thickness=int(t.thickness), a=t.a))
         elif kind == "periodic":
             out["items"].append(dict(kind=kind, axis="XYZ".index(type(t).__name__[-1])))
-        elif kind in ("object", "absorbing", "anisotropic"):
+        elif kind in ("object", "absorbing", "anisotropic", "substrate"):
             d = dict(kind=kind, box=_ints([t.x.start, t.x.stop, t.y.start, t.y.stop, t.z.start, t.z.stop]))
             for field in ("permittivity", "conductivity"):
                 if field in kw:
@@ -622,11 +622,17 @@ def build_oracle(resolved, arrays):
             t = grid.add_pml(it["axis"], it["side"], it["thickness"], it["a"])
         elif k == "periodic":
             t = grid.add_periodic(it["axis"])
-        elif k in ("object", "absorbing", "anisotropic"):
+        elif k in ("object", "absorbing", "anisotropic", "substrate"):
             t = grid.add_object(it["box"], val(it["permittivity"]), kind=k,
                                 conductivity=val(it.get("conductivity")))
-            if it.get("extra"):
+            if it.get("extra") and "offdiag_seed" in it["extra"]:
                 fill_offdiag(t, it["extra"])
+            if k == "substrate":   # the numbers set_modifier_weights gives the engine's convolution
+                rs = np.random.RandomState(it["extra"]["conv_seed"])
+                w = it["extra"]["conv_scale"] * rs.randn(9, 2, 1, 1)
+                b = 0.5 * rs.randn(9)
+                t.modifier_weights[:, 0], t.modifier_weights[:, 1] = w[:, 0, 0, 0], w[:, 1, 0, 0]
+                t.modifier_weights[:, 2] = b
         elif k == "point":
             t = grid.add_point_source(it["cell"], **it["kw"])
         elif k == "line":

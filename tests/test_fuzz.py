@@ -51,14 +51,17 @@ def live_psi(ot):
                      ot.psi_H[u][..., ot.axis], ot.psi_H[v][..., ot.axis]])
 
 
-def check_scene(seed, dtype, big=False, extras=False):
+def check_scene(seed, dtype, big=False, extras=False, substrate=False):
     fdtd.set_backend(f"hip.{dtype}")
-    scene = fuzz_scenes.random_scene(seed, big=big, extras=extras)
+    scene = (fuzz_scenes.random_substrate_scene(seed) if substrate
+             else fuzz_scenes.random_scene(seed, big=big, extras=extras))
     grid, made = scenes.build_api(scene, fdtd)
     resolved, arrays = scenes.resolve(scene, grid, made)
     ogrid, omade = scenes.build_oracle(resolved, arrays)
     errs = {"inv_eps": rel_l2(host(grid.inverse_permittivity), ogrid.inverse_permittivity)}
-    scenes.run_scene(scene, grid)
+    with torch.no_grad() if substrate and seed % 2 else torch.enable_grad():
+        # (a substrate tensor requires grad: half of those scenes run as recorded runs)
+        scenes.run_scene(scene, grid)
     scenes.run_oracle(resolved, ogrid)
     torch.cuda.synchronize()
     if not np.isfinite(ogrid.E).all():
@@ -98,6 +101,18 @@ def test_random_scenes_with_feedback_sources_match_oracle():
     bad = {}
     for seed in range(100, 160):
         out = check_scene(seed, "float64", extras=True)
+        if out and out[0]:
+            bad[seed] = out
+    assert not bad, f"scenes above 1e-12: {bad}"
+
+
+def test_random_scenes_with_a_substrate_object_match_oracle():
+    """Random 2-D scenes with an energy-modulated substrate object (the oracle's version of
+    it equals the reference's torch backend to rounding on such scenes,
+    tools/fuzz_substrate_reference.py); plain and recorded runs."""
+    bad = {}
+    for seed in range(0, 60):
+        out = check_scene(seed, "float64", substrate=True)
         if out and out[0]:
             bad[seed] = out
     assert not bad, f"scenes above 1e-12: {bad}"
