@@ -162,6 +162,42 @@ def test_full_size_translation_invariance(dtype):
     assert torch.equal(fields[0][0], fields[1][0]) and torch.equal(fields[0][1], fields[1][1])
 
 
+def test_offsets_beyond_2_to_31_elements():
+    """1024 x 1024 x 768 float32: 8.1e8 cells, so the element offsets of the field arrays
+    (3 per cell) pass 2^31 from plane 911 on.  A source, a detector and the update itself are
+    exercised beyond that plane: the field around a source at plane 1000 equals, bit for bit,
+    the field around a source at plane 40, and the detector's last reading equals the field
+    at its cells."""
+    fdtd.set_backend("hip.float32")
+    shape, steps, w = (1024, 1024, 768), 8, 8
+    s1, s2 = (40, 300, 200), (1000, 700, 500)
+    assert 3 * (s2[0] - w) * shape[1] * shape[2] > 2 ** 31
+    fields = []
+    for s in (s1, s2):
+        g = fdtd.Grid(shape)
+        for axis in range(3):
+            lo, hi = [slice(None)] * 3, [slice(None)] * 3
+            lo[axis], hi[axis] = slice(0, 10), slice(-10, None)
+            g[tuple(lo)] = fdtd.PML()
+            g[tuple(hi)] = fdtd.PML()
+        g[s] = fdtd.PointSource(period=14)
+        det = fdtd.LineDetector()
+        g[s[0] - 3:s[0] + 4, s[1] + 1, s[2] + 2] = det
+        g.run(steps, progress_bar=False)
+        win = tuple(slice(c - w, c + w) for c in s)
+        fields.append((g.E[win].clone(), g.H[win].clone()))
+        last_E, last_H = det.E[-1], det.H[-1]
+        assert torch.equal(last_E, g.E[s[0] - 3:s[0] + 4, s[1] + 1, s[2] + 2])
+        assert torch.equal(last_H, g.H[s[0] - 3:s[0] + 4, s[1] + 1, s[2] + 2])
+        assert float(last_E.abs().max()) > 0
+        # nothing was written elsewhere: the field is zero outside the light cone
+        far = g.E[s[0] - 3 * w:s[0] - 2 * w] if s[0] > 500 else g.E[s[0] + 2 * w:s[0] + 3 * w]
+        assert float(far.abs().max()) == 0
+        del g, det, far
+        torch.cuda.empty_cache()
+    assert torch.equal(fields[0][0], fields[1][0]) and torch.equal(fields[0][1], fields[1][1])
+
+
 def test_large_grid_kernels_on_small_ragged_shapes():
     """FDTDHIP_FORCE=1 makes the library use its large-grid kernels whatever the plane
     size: every golden scene (2-D, 1-D, ragged extents, all boundary orders) must still
