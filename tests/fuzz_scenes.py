@@ -26,7 +26,9 @@ def _box(rs, shape, max_frac=0.6):
     return tuple(key)
 
 
-def random_scene(seed, big=False, extras=False, floats=False):
+def random_scene(seed, big=False, extras=False, floats=False, crowded=False):
+    """crowded: 8-24 objects, 9-14 sources and 9-13 detectors instead of up to 3 / 3 / 2 (more
+    than any fixed-size batch or table inside the engine holds)."""
     rs = np.random.RandomState(seed)
     dims = rs.choice([1, 2, 3], p=[0.1, 0.4, 0.5])
     lo, hi = (9, 30) if not big else (40, 90)
@@ -73,9 +75,9 @@ def random_scene(seed, big=False, extras=False, floats=False):
 
     # ---- objects (may overlap each other and the PMLs)
     n3 = [n for n in shape if n > 1]
-    for _ in range(int(rs.randint(0, 4))):
+    for _ in range(int(rs.randint(8, 25)) if crowded else int(rs.randint(0, 4))):
         kind = rs.choice(["object", "absorbing", "anisotropic"])
-        key = _box(rs, shape)
+        key = _box(rs, shape, 0.3) if crowded else _box(rs, shape)
         kw = dict(permittivity=float(1.2 + 2.5 * rs.rand()))
         extra = {}
         if kind == "object" and rs.rand() < 0.4:
@@ -101,7 +103,7 @@ def random_scene(seed, big=False, extras=False, floats=False):
                 impedance=float(rs.choice([0.0, 0.1, 0.3])))))
         else:
             items.append(("ccpoint", cell(), dict(dir_vec=tuple(float(v) for v in rs.randn(3)))))
-    for _ in range(int(rs.randint(1, 4))):
+    for _ in range(int(rs.randint(9, 15)) if crowded else int(rs.randint(1, 4))):
         kind = rs.choice(["point", "line", "plane"], p=[0.5, 0.3, 0.2])
         kw = dict(period=int(rs.randint(5, 25)), amplitude=float(0.5 + rs.rand()))
         if rs.rand() < 0.3:
@@ -134,7 +136,7 @@ def random_scene(seed, big=False, extras=False, floats=False):
             items.append(("plane", tuple(key), kw))
 
     # ---- detectors
-    for _ in range(int(rs.randint(0, 3))):
+    for _ in range(int(rs.randint(9, 14)) if crowded else int(rs.randint(0, 3))):
         kind = rs.choice(["linedet", "blockdet", "currentdet"])
         if kind == "linedet":
             a, b = cell(), cell()

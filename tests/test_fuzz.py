@@ -51,10 +51,10 @@ def live_psi(ot):
                      ot.psi_H[u][..., ot.axis], ot.psi_H[v][..., ot.axis]])
 
 
-def check_scene(seed, dtype, big=False, extras=False, substrate=False):
+def check_scene(seed, dtype, big=False, extras=False, substrate=False, crowded=False):
     fdtd.set_backend(f"hip.{dtype}")
     scene = (fuzz_scenes.random_substrate_scene(seed) if substrate
-             else fuzz_scenes.random_scene(seed, big=big, extras=extras))
+             else fuzz_scenes.random_scene(seed, big=big, extras=extras, crowded=crowded))
     grid, made = scenes.build_api(scene, fdtd)
     resolved, arrays = scenes.resolve(scene, grid, made)
     ogrid, omade = scenes.build_oracle(resolved, arrays)
@@ -113,6 +113,17 @@ def test_random_scenes_with_a_substrate_object_match_oracle():
     bad = {}
     for seed in range(0, 60):
         out = check_scene(seed, "float64", substrate=True)
+        if out and out[0]:
+            bad[seed] = out
+    assert not bad, f"scenes above 1e-12: {bad}"
+
+
+def test_random_crowded_scenes_match_oracle():
+    """8-24 overlapping objects, 9-14 sources and 9-13 detectors per scene: more than the
+    engine's fixed-size launch batches and in-kernel tables hold at once."""
+    bad = {}
+    for seed in range(3000, 3040):
+        out = check_scene(seed, "float64", extras=True, crowded=True)
         if out and out[0]:
             bad[seed] = out
     assert not bad, f"scenes above 1e-12: {bad}"

@@ -1,7 +1,7 @@
 """Many seeded random scenes on the HIP engine against the numpy oracle (the checker of
 tests/test_fuzz.py over a wider range of seeds):
 
-    python tools/fuzz_parity.py [first_seed] [count] [float64|float32] [big] [extras] [substrate]
+    python tools/fuzz_parity.py [first_seed] [count] [float64|float32] [big] [extras] [substrate] [crowded]
 
 Kernel choices can be forced from the environment (FDTDHIP_FORCE=1, FDTDHIP_FUSED=0|1).
 """
@@ -19,9 +19,11 @@ dtype = sys.argv[3] if len(sys.argv) > 3 else "float64"
 big = "big" in sys.argv[4:]
 extras = "extras" in sys.argv[4:]
 substrate = "substrate" in sys.argv[4:]
+crowded = "crowded" in sys.argv[4:]
 bad = skipped = 0
 for seed in range(first, first + count):
-    out = test_fuzz.check_scene(seed, dtype, big=big, extras=extras, substrate=substrate)
+    out = test_fuzz.check_scene(seed, dtype, big=big, extras=extras, substrate=substrate,
+                                crowded=crowded)
     if out is None:
         skipped += 1
     elif out[0]:

@@ -23,6 +23,7 @@ sys.path.insert(0, sys.argv[3] if len(sys.argv) > 3 else "/root/reference")
 os.environ.setdefault("MPLBACKEND", "Agg")
 
 EXTRAS = os.environ.get("FUZZ_EXTRAS") == "1"   # soft and direction-vector point sources too
+CROWDED = os.environ.get("FUZZ_CROWDED") == "1"  # many objects, sources and detectors per scene
 
 import fdtd as ref  # noqa: E402  (the real reference)
 
@@ -44,7 +45,7 @@ def same(a, b, what):
 
 
 def one(seed):
-    scene = fuzz_scenes.random_scene(seed, extras=EXTRAS)
+    scene = fuzz_scenes.random_scene(seed, extras=EXTRAS, crowded=CROWDED)
     ref.set_backend("numpy")
     with contextlib.redirect_stdout(io.StringIO()):
         rgrid, rmade = scenes.build_api(scene, ref)
@@ -83,7 +84,7 @@ for seed in range(first, first + count):
             print(f"seed {seed}: non-finite fields (still equal)")
     except Differs as e:
         bad += 1
-        print(f"seed {seed}: ORACLE DIFFERS FROM REFERENCE: {e}\n   {fuzz_scenes.random_scene(seed, extras=EXTRAS)}")
+        print(f"seed {seed}: ORACLE DIFFERS FROM REFERENCE: {e}\n   {fuzz_scenes.random_scene(seed, extras=EXTRAS, crowded=CROWDED)}")
     except Exception:  # noqa: BLE001 -- a scene the reference itself refuses is a generator bug
         skipped += 1
         print(f"seed {seed}: construction/run error\n{traceback.format_exc(limit=3)}")
