@@ -45,6 +45,8 @@ PROTOTYPES = {
     "fdtdhip_plan_set_modulated_source": (_i, [_p, _i, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
     "fdtdhip_plan_add_detector": (_i, [_p, _i, _i64, _pi32, _d]),
     "fdtdhip_plan_set_detector_output": (_i, [_p, _i, _p, _p, _i64]),
+    "fdtdhip_plan_set_detector_below": (_i, [_p, _i, _p]),
+    "fdtdhip_read_deferred_currents": (_i, [_p]),
     "fdtdhip_update_E": (_i, [_p, _i64]),
     "fdtdhip_update_H": (_i, [_p, _i64]),
     "fdtdhip_update_E_bulk": (_i, [_p, _i, _i]),

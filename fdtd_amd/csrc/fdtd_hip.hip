@@ -113,6 +113,7 @@ struct DetH {
   int64_t* cell = nullptr;  // device flat cell index (CELLS)
   std::vector<int64_t> cell_host;
   int32_t* xyz = nullptr;   // device (CURRENT)
+  const void* below = nullptr;  // CURRENT on an x-slab: the H plane under plane 0; read on request only
   double spacing;
   char* outE = nullptr;
   char* outH = nullptr;
@@ -596,6 +597,19 @@ void advance_trace_cursor(fdtdhip_plan* p) {
     if (o.trace && p->trace_cursor >= o.trace_capacity) p->trace_cursor = -1;  // traces full
 }
 
+// One reading of a loop-current detector from the present H field.
+template <typename T>
+int read_current(fdtdhip_plan* p, DetH& d) {
+  if (d.n == 0) { ++d.usedH; return 0; }
+  if (!d.outH || d.usedH >= d.capacity) return fail(-3, "detector output capacity exhausted");
+  T* out = (T*)d.outH + d.usedH * d.n;
+  hipLaunchKernelGGL((detect_current<T>), dim3(blocks_for(d.n, 64)), dim3(64), 0, p->stream,
+                     (const T*)p->H, (const T*)d.below, d.xyz, out, d.n, p->nx, p->ny, p->nz,
+                     (T)d.spacing);
+  ++d.usedH;
+  return 0;
+}
+
 template <typename T>
 int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 = 0, int x1 = -1,
          int stage = -1) {
@@ -711,16 +725,22 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
       batch.first[batch.count + 1] = batch.first[batch.count] + d.n * 3;
       if (++batch.count == MAX_DET_BATCH) flush();
       ++used;
-    } else if (!phaseE) {
-      if (d.n == 0) { ++d.usedH; continue; }
-      if (!d.outH || d.usedH >= d.capacity) { flush(); return fail(-3, "detector output capacity exhausted"); }
-      T* out = (T*)d.outH + d.usedH * d.n;
-      hipLaunchKernelGGL((detect_current<T>), dim3(blocks_for(d.n, 64)), dim3(64), 0, p->stream,
-                         (const T*)p->H, d.xyz, out, d.n, p->nx, p->ny, p->nz, (T)d.spacing);
-      ++d.usedH;
+    } else if (!phaseE && !d.below) {
+      if (int rc = read_current<T>(p, d)) { flush(); return rc; }
     }
   }
   flush();
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// The current detectors that wait for the plane under the slab (fdtdhip_plan_set_detector_below).
+template <typename T>
+int read_deferred_currents(fdtdhip_plan* p) {
+  if (!p->H) return fail(-1, "fields not set");
+  for (DetH& d : p->dets)
+    if (d.kind == FDTDHIP_DET_CURRENT && d.below)
+      if (int rc = read_current<T>(p, d)) return rc;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1463,6 +1483,20 @@ int fdtdhip_plan_set_detector_output(fdtdhip_plan* p, int id, void* outE, void* 
   d.capacity = capacity;
   d.usedE = d.usedH = 0;
   return 0;
+}
+
+int fdtdhip_plan_set_detector_below(fdtdhip_plan* p, int id, const void* H_plane) {
+  if (!p) return fail(-1, "null plan");
+  if (id < 0 || id >= (int)p->dets.size()) return fail(-1, "unknown detector id");
+  if (p->dets[id].kind != FDTDHIP_DET_CURRENT) return fail(-1, "not a current detector");
+  p->dets[id].below = H_plane;
+  return 0;
+}
+
+int fdtdhip_read_deferred_currents(fdtdhip_plan* p) {
+  if (!p) return fail(-1, "null plan");
+  DeviceGuard g(p->device);
+  return DISPATCH(p, read_deferred_currents<float>(p), read_deferred_currents<double>(p));
 }
 
 int fdtdhip_update_E_bulk(fdtdhip_plan* p, int x0, int x1) {

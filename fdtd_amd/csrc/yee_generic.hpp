@@ -512,8 +512,8 @@ __global__ void detect_cells_batch(const T* F, DetBatch<T> b) {
 // carry of the first layer's Hy term into the second layer (line 456) and
 // Python's wrap-around for index -1.
 template <typename T>
-__global__ void detect_current(const T* H, const int32_t* xyz, T* out, int64_t n, int nx, int ny,
-                               int nz, T spacing) {
+__global__ void detect_current(const T* H, const T* below, const int32_t* xyz, T* out, int64_t n,
+                               int nx, int ny, int nz, T spacing) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const int px = xyz[3 * t], py = xyz[3 * t + 1], pz = xyz[3 * t + 2];
@@ -523,11 +523,15 @@ __global__ void detect_current(const T* H, const int32_t* xyz, T* out, int64_t n
   auto at = [&](int i, int j, int k, int c) {
     return H[(((int64_t)i * ny + j) * nz + k) * 3 + c];
   };
+  // plane px - 1: on an x-slab the plane under plane 0 belongs to another rank (`below`)
+  auto under = [&](int j, int k, int c) {
+    return px == 0 && below ? below[((int64_t)j * nz + k) * 3 + c] : at(xm, j, k, c);
+  };
   T v1 = (at(px, ym, pz, 0) - at(px, py, pz, 0)) * spacing;
-  T v2 = (at(px, py, pz, 1) - at(xm, py, pz, 1)) * spacing;
+  T v2 = (at(px, py, pz, 1) - under(py, pz, 1)) * spacing;
   const T cur1 = v1 + v2;
   v1 = (at(px, ym, zm, 0) - at(px, py, zm, 0)) * spacing;
-  v2 += (at(px, py, zm, 1) - at(xm, py, zm, 1)) * spacing;
+  v2 += (at(px, py, zm, 1) - under(py, zm, 1)) * spacing;
   const T cur2 = v1 + v2;
   out[t] = (cur1 + cur2) / T(2);
 }

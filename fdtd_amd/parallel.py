@@ -71,6 +71,17 @@ class _NativeEngine:
     def post_H_stage(self, q, stage):
         _lib.check(self.lib.fdtdhip_update_H_post_stage(self.plan, q, stage))
 
+    def defer_currents(self, plane):
+        """Current detectors wait for ``plane`` (the H plane under this slab) instead of
+        being read with the other detectors; None: read them with the others."""
+        ptr = ctypes.c_void_p(plane.data_ptr()) if plane is not None else None
+        for det in self.grid.detectors:
+            if det._kind == _lib.DET_CURRENT:
+                _lib.check(self.lib.fdtdhip_plan_set_detector_below(self.plan, det._id, ptr))
+
+    def read_deferred_currents(self):
+        _lib.check(self.lib.fdtdhip_read_deferred_currents(self.plan))
+
 
 class _Exchange:
     """One in-flight neighbour exchange (send one plane, receive one plane)."""
@@ -141,6 +152,20 @@ class SlabGrid(Grid):
         return self._world > 1 and any(
             getattr(b, "axis", None) == 0 and not hasattr(b, "thickness") for b in self.boundaries)
 
+    @property
+    def _currents_cross_slabs(self):
+        """Whether a CurrentDetector holds a cell on the first plane of some rank's slab.
+        Its loop reads H of plane x-1 (reference fdtd/detectors.py:452-459; index -1 wraps
+        to the last plane of the simulation), which is the last plane of the rank below,
+        as that rank leaves it at the end of the H half step.  The same answer on every rank."""
+        if self._world == 1:
+            return False
+        base, extra = divmod(self.Nx_global, self._world)
+        firsts = {r * base + min(r, extra) for r in range(self._world)}
+        return any(getattr(d, "_kind", None) == _lib.DET_CURRENT
+                   and any(self._cell_index(x, self.Nx_global) in firsts for x in d.x)
+                   for d in self.detectors)
+
     # ------------------------------------------------------------ halo exchange
     def _start_exchange(self, send, dst, recv, src):
         """Send plane ``send`` to rank ``dst`` and receive into ``recv`` from rank ``src``
@@ -187,6 +212,11 @@ class SlabGrid(Grid):
 
     def _half_step_H(self, eng, q):
         r, p = self._rank, self._world
+        cross = self._currents_cross_slabs
+        if cross:
+            if getattr(self, "_H_ring", None) is None:
+                self._H_ring = bd.zeros((self.Ny, self.Nz, 3))
+            eng.defer_currents(self._H_ring)   # before the post pieces: they leave these out
         ex = self._start_exchange(self.E[0] if r > 0 else None, r - 1,
                                   self._E_above, r + 1)
         last = self.Nx - 1 if r < p - 1 else self.Nx
@@ -205,6 +235,10 @@ class SlabGrid(Grid):
             eng.post_H_stage(q, 1)
         else:
             eng.post_H(q)
+        if cross:
+            ex = self._start_exchange(self.H[-1], (r + 1) % p, self._H_ring, (r - 1) % p)
+            ex.wait()
+            eng.read_deferred_currents()
 
     def update_E(self):
         self._no_half_step_autograd()

@@ -195,6 +195,16 @@ int fdtdhip_plan_add_detector(fdtdhip_plan* plan, int kind, int64_t n,
 int fdtdhip_plan_set_detector_output(fdtdhip_plan* plan, int id, void* outE, void* outH,
                                      int64_t capacity);
 
+/* Loop-current detector on an x-slab (no reference counterpart: the reference is single
+ * device).  The current of a cell reads H of plane x-1 (reference fdtd/detectors.py:452-459,
+ * index -1 wrapping to the last plane of the simulation); for plane 0 of a slab that plane
+ * is another rank's last one.  `H_plane`: device (ny,nz,3) copy of it.  A detector with such a
+ * plane is left out of the update_H post pieces: the caller fills the plane once those have
+ * run on the owning rank and then calls fdtdhip_read_deferred_currents, which takes one
+ * reading of every such detector.  NULL restores the single-grid behaviour. */
+int fdtdhip_plan_set_detector_below(fdtdhip_plan* plan, int id, const void* H_plane);
+int fdtdhip_read_deferred_currents(fdtdhip_plan* plan);
+
 /* Half steps (reference fdtd/grid.py:275-299 and 301-325); q =
  * Grid.time_steps_passed. */
 int fdtdhip_update_E(fdtdhip_plan* plan, int64_t q);

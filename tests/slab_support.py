@@ -99,6 +99,26 @@ class OracleSlabEngine:
     def reserve_detectors(self, nE, nH):
         pass
 
+    # -- current detectors whose loop reads the plane under the slab
+    def defer_currents(self, plane):
+        self.below = plane
+
+    def _detect_H(self):
+        for d in self.og.detectors:
+            if not (isinstance(d, orc.OracleCurrentDetector) and getattr(self, "below", None) is not None):
+                d.detect_H()
+
+    def read_deferred_currents(self):
+        # index -1 of the slab's H with the plane from below appended is that plane
+        og = self.og
+        stacked = np.concatenate([og.H, self.below.numpy()[None]], axis=0)
+        for d in og.detectors:
+            if isinstance(d, orc.OracleCurrentDetector):
+                assert all(0 <= x < og.Nx for x in d.x)
+                d.grid = type("WithPlaneBelow", (), dict(H=stacked, grid_spacing=og.grid_spacing))
+                d.detect_H()
+                d.grid = og
+
     def commit_detectors(self, nE, nH):
         for d, od in self.dets:
             for attr in ("E", "H", "I"):
@@ -142,7 +162,13 @@ class OracleSlabEngine:
         g, og = self.grid, self.og
         og.time_steps_passed = q
         og.halo_hi_E = g._E_above.numpy() if g._E_above is not None else None
-        og.update_H()
+        if getattr(self, "below", None) is None:
+            og.update_H()
+        else:   # the statements of OracleGrid.update_H with the current detectors left out
+            dets, og.detectors = og.detectors, []
+            og.update_H()
+            og.detectors = dets
+            self._detect_H()
 
     # -- the same half steps cut at the cross-rank periodic boundary (the statements of
     #    OracleGrid.update_E / update_H, reference fdtd/grid.py:275-325)
@@ -183,8 +209,7 @@ class OracleSlabEngine:
                 b.update_H()
             for s in og.sources:
                 s.update_H()
-            for d in og.detectors:
-                d.detect_H()
+            self._detect_H()
 
 
 def free_port():

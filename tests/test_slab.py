@@ -221,13 +221,14 @@ def test_partition_arithmetic():
         Fake(3, 4, 0)
 
 
-def _fuzz(world, first, count, on_gpu, tmp_path):
+def _fuzz(world, first, count, on_gpu, tmp_path, crowded=False):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_slab
 
-    seeds, bad = fuzz_slab.run(world, first, count, on_gpu, str(tmp_path / "fuzz.npz"))
+    seeds, bad = fuzz_slab.run(world, first, count, on_gpu, str(tmp_path / "fuzz.npz"), crowded)
     assert len(seeds) >= count // 3
     assert not bad, bad
+    return sum(fuzz_slab.crosses(fuzz_slab.make_scene(s, crowded), world) for s in seeds)
 
 
 def test_random_scenes_on_slabs_cpu(tmp_path):
@@ -235,6 +236,20 @@ def test_random_scenes_on_slabs_cpu(tmp_path):
     (plane ranges, ghost planes, cross-rank periodic copy, split objects and boundaries)
     over the oracle engine must reproduce the single-grid oracle."""
     _fuzz(2, 0, 24, False, tmp_path)
+
+
+def test_crowded_scenes_on_slabs_cpu(tmp_path):
+    """Scenes with many objects, sources and detectors on three ranks; fields and every
+    detector's readings.  Several hold a CurrentDetector cell on the first plane of a slab:
+    its loop reads the last H plane of the rank below (for plane 0 of the simulation: of
+    the last rank, index -1 of reference fdtd/detectors.py:452-459), which the ranks pass
+    round once the H half step is complete."""
+    assert _fuzz(3, 5000, 14, False, tmp_path, crowded=True) >= 3
+
+
+@pytest.mark.gpu
+def test_crowded_scenes_on_slabs_gpu(tmp_path):
+    assert _fuzz(3, 5000, 60, True, tmp_path, crowded=True) >= 10
 
 
 @pytest.mark.gpu

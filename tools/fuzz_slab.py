@@ -4,9 +4,10 @@
 
 `world` ranks over gloo.  gpu: every rank drives the HIP engine on GPU 0 (ghost planes,
 plane ranges, the cross-rank x-periodic copy); cpu: the slab host logic over the oracle
-engine of tests/slab_support.py.  The gathered E and H must equal the oracle's single-grid
-result to 1e-12 (float64).  Scenes whose x-PML is thicker than the thinnest slab, or with
-a detector that reads across a slab face (CurrentDetector), are left out.
+engine of tests/slab_support.py.  The gathered E and H and every detector's readings
+(each rank's part, joined in rank order) must equal the oracle's single-grid result to
+1e-12 (float64).  Scenes whose x-PML is thicker than the thinnest slab are left out.
+FUZZ_BIG=1: extents of 40-128 cells; FUZZ_CROWDED=1: many objects, sources and detectors.
 """
 import os
 import sys
@@ -23,6 +24,18 @@ import scenes  # noqa: E402
 import slab_support  # noqa: E402
 
 BIG = os.environ.get("FUZZ_BIG") == "1"     # extents of 40-128 cells (planes for the fast kernels)
+CROWDED = os.environ.get("FUZZ_CROWDED") == "1"
+DETECTORS = {"linedet": ("E", "H"), "blockdet": ("E", "H"), "currentdet": ("I",)}
+
+
+def make_scene(seed, crowded=None):
+    return fuzz_scenes.random_scene(seed, big=BIG, crowded=CROWDED if crowded is None else crowded)
+
+
+def stacked(readings):
+    """A detector's list of readings as one array (steps, cells along x or points, ...)."""
+    return np.array([np.asarray(r.detach().cpu()) if torch.is_tensor(r) else np.asarray(r)
+                     for r in readings], dtype=np.float64)
 
 
 def usable(scene, world):
@@ -32,8 +45,6 @@ def usable(scene, world):
     thinnest = nx // world
     for item in scene["items"]:
         kind, key = item[0], item[1]
-        if kind == "currentdet":
-            return False
         if kind == "pml" and isinstance(key[0], slice) and (key[0].start, key[0].stop) != (None, None):
             t = key[0].stop if key[0].stop is not None else -key[0].start
             if t > thinnest:
@@ -41,7 +52,16 @@ def usable(scene, world):
     return True
 
 
-def worker(rank, world, port, seeds, on_gpu, out):
+def crosses(scene, world):
+    """Whether a current detector sits on the first plane of some rank's slab (its loop
+    then reads the plane of the rank below)."""
+    nx = scene["grid"]["shape"][0]
+    base, extra = divmod(nx, world)
+    firsts = {r * base + min(r, extra) for r in range(world)}
+    return any(item[0] == "currentdet" and item[1][0] in firsts for item in scene["items"])
+
+
+def worker(rank, world, port, seeds, on_gpu, out, crowded=None):
     import torch.distributed as dist
 
     import fdtd_amd as fdtd
@@ -57,7 +77,7 @@ def worker(rank, world, port, seeds, on_gpu, out):
             factory = slab_support.OracleSlabEngine
         results = {}
         for seed in seeds:
-            scene = fuzz_scenes.random_scene(seed, big=BIG)
+            scene = make_scene(seed, crowded)
             grid, made = scenes.build_api(
                 scene, fdtd, grid_factory=lambda **kw: SlabGrid(engine_factory=factory, **kw))
             half = scene["steps"] // 2
@@ -69,34 +89,49 @@ def worker(rank, world, port, seeds, on_gpu, out):
             if on_gpu:
                 torch.cuda.synchronize()
             E, H = grid.gather("E"), grid.gather("H")
+            mine = {}
+            for n, item in enumerate(made):
+                for attr in DETECTORS.get(item[0], ()):
+                    mine[f"det{n}_{attr}"] = stacked(getattr(item[1], attr))
+            parts = [None] * world
+            dist.all_gather_object(parts, mine)
             if rank == 0:
                 results[f"E{seed}"], results[f"H{seed}"] = E, H
+                for key in mine:   # the ranks hold consecutive cells of the detector
+                    results[f"{key}_{seed}"] = np.concatenate([p[key] for p in parts], axis=1)
         if rank == 0:
             np.savez(out, **results)
     finally:
         dist.destroy_process_group()
 
 
-def oracle_fields(scene):
+def oracle_results(scene):
     import fdtd_amd as fdtd
 
     fdtd.set_backend("hip.float64", device="host-staging")
     g, made = scenes.build_api(scene, fdtd)
     resolved, arrays = scenes.resolve(scene, g, made)
-    og, _ = scenes.build_oracle(resolved, arrays)
+    og, omade = scenes.build_oracle(resolved, arrays)
     scenes.run_oracle(resolved, og)
-    return og.E, og.H
+    want = {"E": og.E, "H": og.H}
+    for n, item in enumerate(omade):
+        for attr in DETECTORS.get(made[n][0], ()):
+            want[f"det{n}_{attr}"] = stacked(getattr(item[1], attr))
+    return want
 
 
-def run(world, first, count, on_gpu, out):
-    seeds = [s for s in range(first, first + count) if usable(fuzz_scenes.random_scene(s, big=BIG), world)]
-    mp.spawn(worker, args=(world, slab_support.free_port(), seeds, on_gpu, out), nprocs=world, join=True)
+def run(world, first, count, on_gpu, out, crowded=None):
+    seeds = [s for s in range(first, first + count) if usable(make_scene(s, crowded), world)]
+    mp.spawn(worker, args=(world, slab_support.free_port(), seeds, on_gpu, out, crowded), nprocs=world, join=True)
     z = np.load(out)
     bad = {}
     for seed in seeds:
-        E, H = oracle_fields(fuzz_scenes.random_scene(seed, big=BIG))
-        for name, want in (("E", E), ("H", H)):
-            got = z[f"{name}{seed}"]
+        for name, want in oracle_results(make_scene(seed, crowded)).items():
+            got = z[f"{name}{seed}"] if name in ("E", "H") else z[f"{name}_{seed}"]
+            got = got.reshape(want.shape) if got.size == want.size else got
+            if got.shape != want.shape:
+                bad.setdefault(seed, {})[name] = f"shape {got.shape} for {want.shape}"
+                continue
             n = np.linalg.norm(want.ravel())
             err = np.linalg.norm((got - want).ravel()) / (n if n > 0 else 1.0)
             if not err <= 1e-12:
@@ -109,6 +144,8 @@ if __name__ == "__main__":
     on_gpu = len(sys.argv) > 4 and sys.argv[4] == "gpu"
     seeds, bad = run(world, first, count, on_gpu, f"/tmp/fuzz_slab_{os.getpid()}.npz")
     for seed, errs in bad.items():
-        print(f"seed {seed}: {errs}\n   {fuzz_scenes.random_scene(seed, big=BIG)}")
-    print(f"x{world} {'gpu' if on_gpu else 'cpu'}: {len(seeds)} scenes, {len(bad)} above 1e-12")
+        print(f"seed {seed}: {errs}\n   {make_scene(seed)}")
+    print(f"x{world} {'gpu' if on_gpu else 'cpu'}: {len(seeds)} scenes "
+          f"({sum(crosses(make_scene(s), world) for s in seeds)} with a current loop across slabs), "
+          f"{len(bad)} above 1e-12")
     sys.exit(1 if bad else 0)
