@@ -7,7 +7,7 @@ scene (tests/fuzz_scenes.py); the loss is a random-weight quadratic form of the 
 (each rank its planes).  Loss and the object's tensor gradient, concatenated along x, must
 equal what the same engine gives on one undivided grid (relative L2 <= 1e-12).  Scenes are
 left out when the slab adjoint does not cover them: an x-periodic boundary (crosses ranks),
-an x-PML thicker than the thinnest slab, a loop-current detector.
+an x-PML thicker than the thinnest slab.
 """
 import os
 import sys
