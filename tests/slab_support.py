@@ -18,6 +18,31 @@ import torch
 from oracle import yee_numpy as orc
 
 
+class _SlabDirectionalPoint:
+    """The six additions of OracleCCPointSource.update_E (reference fdtd/sources.py:150-167),
+    each made by the rank whose slab holds its plane (index -1 wraps around the whole
+    simulation)."""
+
+    def __init__(self, g, og, s):
+        self.g, self.og = g, og
+        d = [float(v) for v in s.dir_vec]
+        x, y, z = int(s.x), int(s.y), int(s.z)
+        self.terms = [((x - 1, y, z), -d[0]), ((x, y, z), d[0]), ((x, y - 1, z), -d[1]),
+                      ((x, y, z), d[1]), ((x, y, z - 1), -d[2]), ((x, y, z), d[2])]
+        self.period = s.period
+
+    def update_E(self):
+        g, og = self.g, self.og
+        src = np.sin(2 * np.pi * og.time_steps_passed / self.period)
+        for (x, y, z), w in self.terms:
+            xl = g._local_x(x % g.Nx_global)
+            if xl is not None:
+                og.E[xl, y, z, 2] += src * w
+
+    def update_H(self):
+        pass
+
+
 class OracleSlabEngine:
     def __init__(self, grid):
         self.grid = grid
@@ -75,6 +100,8 @@ class OracleSlabEngine:
                                        hanning_dt=s.hanning_dt)
                 t.wave.frequency = s.frequency
                 t.profile = np.array([s.profile[n] for n in keep])
+            elif name == "CorticalColumnPointSource":
+                og.sources.append(_SlabDirectionalPoint(g, og, s))
             elif name == "PlaneSource":
                 lo, hi = g._clip_x(s.x.start, s.x.stop)
                 if hi <= lo:
@@ -82,6 +109,8 @@ class OracleSlabEngine:
                 og.add_plane_source((lo, hi, s.y.start, s.y.stop, s.z.start, s.z.stop),
                                     period=s.period, amplitude=s.amplitude,
                                     phase_shift=s.phase_shift, polarization=s.polarization)
+            else:
+                raise NotImplementedError(f"{name} in the oracle slab engine")
         for d in g.detectors:
             name = type(d).__name__
             if name == "LineDetector":

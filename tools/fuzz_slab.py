@@ -6,8 +6,10 @@
 plane ranges, the cross-rank x-periodic copy); cpu: the slab host logic over the oracle
 engine of tests/slab_support.py.  The gathered E and H and every detector's readings
 (each rank's part, joined in rank order) must equal the oracle's single-grid result to
-1e-12 (float64).  Scenes whose x-PML is thicker than the thinnest slab are left out.
-FUZZ_BIG=1: extents of 40-128 cells; FUZZ_CROWDED=1: many objects, sources and detectors.
+1e-12 (float64).  Scenes whose x-PML is thicker than the thinnest slab are left out (refused
+at registration), and so are those with a SoftArbitraryPointSource (refused as well).
+FUZZ_BIG=1: extents of 40-128 cells; FUZZ_CROWDED=1: many objects, sources and detectors;
+FUZZ_EXTRAS=1: direction-vector point sources in some scenes.
 """
 import os
 import sys
@@ -25,11 +27,13 @@ import slab_support  # noqa: E402
 
 BIG = os.environ.get("FUZZ_BIG") == "1"     # extents of 40-128 cells (planes for the fast kernels)
 CROWDED = os.environ.get("FUZZ_CROWDED") == "1"
+EXTRAS = os.environ.get("FUZZ_EXTRAS") == "1"   # direction-vector point sources too
 DETECTORS = {"linedet": ("E", "H"), "blockdet": ("E", "H"), "currentdet": ("I",)}
 
 
 def make_scene(seed, crowded=None):
-    return fuzz_scenes.random_scene(seed, big=BIG, crowded=CROWDED if crowded is None else crowded)
+    return fuzz_scenes.random_scene(seed, big=BIG, extras=EXTRAS,
+                                    crowded=CROWDED if crowded is None else crowded)
 
 
 def stacked(readings):
@@ -45,6 +49,8 @@ def usable(scene, world):
     thinnest = nx // world
     for item in scene["items"]:
         kind, key = item[0], item[1]
+        if kind == "soft":     # SoftArbitraryPointSource refuses slab grids
+            return False
         if kind == "pml" and isinstance(key[0], slice) and (key[0].start, key[0].stop) != (None, None):
             t = key[0].stop if key[0].stop is not None else -key[0].start
             if t > thinnest:
