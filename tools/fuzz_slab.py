@@ -28,11 +28,17 @@ import slab_support  # noqa: E402
 BIG = os.environ.get("FUZZ_BIG") == "1"     # extents of 40-128 cells (planes for the fast kernels)
 CROWDED = os.environ.get("FUZZ_CROWDED") == "1"
 EXTRAS = os.environ.get("FUZZ_EXTRAS") == "1"   # direction-vector point sources too
+FLOATS = os.environ.get("FUZZ_FLOATS") == "1"   # some keys, extents and periods in metres / seconds
 DETECTORS = {"linedet": ("E", "H"), "blockdet": ("E", "H"), "currentdet": ("I",)}
 
 
+SUBSTRATE = os.environ.get("FUZZ_SUBSTRATE") == "1"   # 2-D scenes with an energy-modulated object (GPU only)
+
+
 def make_scene(seed, crowded=None):
-    return fuzz_scenes.random_scene(seed, big=BIG, extras=EXTRAS,
+    if SUBSTRATE:
+        return fuzz_scenes.random_substrate_scene(seed)
+    return fuzz_scenes.random_scene(seed, big=BIG, extras=EXTRAS, floats=FLOATS,
                                     crowded=CROWDED if crowded is None else crowded)
 
 
@@ -88,10 +94,11 @@ def worker(rank, world, port, seeds, on_gpu, out, crowded=None):
                 scene, fdtd, grid_factory=lambda **kw: SlabGrid(engine_factory=factory, **kw))
             half = scene["steps"] // 2
             grid.run(half)
-            for _ in range(scene["steps"] - half):  # the half-step entry points too
-                grid.update_E()
-                grid.update_H()
-                grid.time_steps_passed += 1
+            with torch.no_grad():   # (half steps are not recorded for a backward pass)
+                for _ in range(scene["steps"] - half):  # the half-step entry points too
+                    grid.update_E()
+                    grid.update_H()
+                    grid.time_steps_passed += 1
             if on_gpu:
                 torch.cuda.synchronize()
             E, H = grid.gather("E"), grid.gather("H")
