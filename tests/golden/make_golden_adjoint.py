@@ -1,6 +1,6 @@
 """Golden gradients for the differentiable runs, from the real reference.
 
-    PYTHONPATH=/root/repo python tests/golden/make_golden_adjoint.py [/root/reference]
+    PYTHONPATH=/root/repo python tests/golden/make_golden_adjoint.py [/root/reference [scene ...]]
 
 Runs every scene of ``scenes.ADJOINT_SCENES`` with the reference's ``torch`` (CPU,
 float64) backend, back-propagates the scene's loss with torch autograd exactly as
@@ -33,6 +33,8 @@ import scenes  # noqa: E402
 def main():
     ref.set_backend("torch")
     for name, scene in scenes.ADJOINT_SCENES.items():
+        if sys.argv[2:] and name not in sys.argv[2:]:
+            continue
         with contextlib.redirect_stdout(io.StringIO()):
             grid, made = scenes.build_api(scene, ref)
             for n in scene["chunks"]:

@@ -377,6 +377,38 @@ ADJOINT_SCENES = {
         steps=30, chunks=(1, 1, 1, 12, 15),
         loss=dict(kind="dense", seed=7),
     ),
+    # other shapes of the same set-up: seven columns on a ragged plane that a substrate and an
+    # absorbing object cover in part, PMLs along y
+    "adjoint_cortical2d_b": dict(
+        grid=dict(shape=(33, 29, 1), permittivity=1.2),
+        items=[
+            ("pml",       (S(None), S(0, 4), S(None)), {}),
+            ("periodic",  (S(None), S(None), 0), {}),
+            ("pml",       (S(None), S(-3, None), S(None)), {}),
+            ("cortical",  (S(6, 27), S(5, 22), 0), dict(period=10, polarization="y", num_cortical_columns=7),
+             dict(seed=31, conv_scale=60.0, amp=0.08)),
+            ("substrate", (S(10, 30), S(6, 20), S(None)), dict(permittivity=2.1),
+             dict(offdiag_seed=14, offdiag_scale=0.04, conv_seed=15, conv_scale=40.0)),
+            ("absorbing", (S(3, 12), S(8, 15), S(None)), dict(permittivity=1.6, conductivity=2e4)),
+            ("learnable", (S(20, 31), S(15, 25), S(None)), dict(permittivity=1.9), dict(offdiag_seed=16, offdiag_scale=0.03)),
+            ("line",      (S(4, 9), S(6, 24), 0), dict(period=11, amplitude=0.4)),
+        ],
+        steps=22, chunks=(2, 11, 9),
+        loss=dict(kind="dense", seed=8),
+    ),
+    # a single column, no substrate: the source alone drives a learnable object
+    "adjoint_cortical2d_c": dict(
+        grid=dict(shape=(21, 26, 1)),
+        items=[
+            ("cortical",  (S(3, 17), S(4, 21), 0), dict(period=9, polarization="x", num_cortical_columns=1),
+             dict(seed=41, conv_scale=200.0, amp=0.1)),
+            ("learnable", (S(8, 19), S(9, 24), S(None)), dict(permittivity=2.2), dict(offdiag_seed=17, offdiag_scale=0.05)),
+            ("pml",       (S(0, 3), S(None), S(None)), {}),
+            ("pml",       (S(-2, None), S(None), S(None)), {}),
+        ],
+        steps=16, chunks=(7, 9),
+        loss=dict(kind="dense", seed=9),
+    ),
 }
 
 
