@@ -247,6 +247,7 @@ class SlabGrid(Grid):
         eng.reserve_detectors(1, 0)
         self._half_step_E(eng, self.time_steps_passed)
         eng.commit_detectors(1, 0)
+        self._finish_sources(1)
 
     def update_H(self):
         self._no_half_step_autograd()
@@ -296,6 +297,7 @@ class SlabGrid(Grid):
             self._half_step_E(eng, q)
             self._half_step_H(eng, q)
         eng.commit_detectors(n, n)
+        self._finish_sources(n)
 
     # ----------------------------------------------------------------- adjoint
     def _native_adjoint(self, lib, n, lamE, lamH, work):

@@ -413,7 +413,9 @@ class SoftArbitraryPointSource:
     grid_spacing`` to Ez, ``I`` being the reading its own ``CurrentDetector`` (registered at
     the same cell, ``self.current_detector``) took after the previous step.  The feedback
     runs on the device; ``input_voltage`` and ``source_voltage`` are lists of per-step
-    device scalars of shape (1, 1, 1), like the reference's nested lists."""
+    device scalars of shape (1, 1, 1), like the reference's nested lists.  On an x-slab grid
+    the rank whose slab holds the cell runs the source and fills the two lists; on the other
+    ranks they stay empty."""
 
     _no_autograd = "a source fed back from its current detector"
 
@@ -431,9 +433,6 @@ class SoftArbitraryPointSource:
     def _register_grid(self, grid: Grid, x: Number, y: Number, z: Number):
         from .detectors import CurrentDetector, _Readings
 
-        if grid.Nx != grid.Nx_global:
-            raise NotImplementedError(
-                "SoftArbitraryPointSource is not available on an x-slab decomposed grid")
         self.grid = grid
         grid.sources.append(self)
         grid._claim_name(self)
@@ -458,16 +457,24 @@ class SoftArbitraryPointSource:
         w = np.ascontiguousarray(
             bd.numpy(self.waveform_array) if torch.is_tensor(self.waveform_array)
             else self.waveform_array, dtype=np.float64).reshape(-1)
-        cell = [g._cell_index(self.x, g.Nx), g._cell_index(self.y, g.Ny), g._cell_index(self.z, g.Nz)]
+        # on x-slabs the rank that holds the cell runs the source and keeps its two records
+        xl = g._local_x(g._cell_index(self.x, g.Nx_global))
+        self._native_id = None
+        if xl is None:
+            return
+        cell = [xl, g._cell_index(self.y, g.Ny), g._cell_index(self.z, g.Nz)]
         self._native_id = _lib.check(lib.fdtdhip_plan_add_soft_source(
             plan, _lib.int32s(cell), w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), w.size,
             float(self.impedance), float(g.grid_spacing)))
 
     def _native_link(self, lib, plan):
         """After all components are in the plan: name the detector that feeds this source."""
-        _lib.check(lib.fdtdhip_plan_link_soft_source(plan, self._native_id, self.current_detector._id))
+        if self._native_id is not None:
+            _lib.check(lib.fdtdhip_plan_link_soft_source(plan, self._native_id, self.current_detector._id))
 
     def _native_prepare(self, lib, plan, q0, n):
+        if self._native_id is None:
+            return
         last = self.current_detector.I[-1] if len(self.current_detector.I) else None
         pin, pout = self._vin.reserve(n), self._vout.reserve(n)
         _lib.check(lib.fdtdhip_plan_set_soft_source_io(
@@ -475,6 +482,8 @@ class SoftArbitraryPointSource:
             ctypes.c_void_p(pin), ctypes.c_void_p(pout), n))
 
     def _native_finish(self, n):
+        if self._native_id is None:
+            return
         self._vin.commit(n, self.input_voltage)
         self._vout.commit(n, self.source_voltage)
 

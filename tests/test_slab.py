@@ -253,6 +253,16 @@ def test_crowded_scenes_on_slabs_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_scenes_with_feedback_sources_on_slabs_gpu(tmp_path, monkeypatch):
+    """Scenes with a SoftArbitraryPointSource (run by the rank that holds its cell, fed by its
+    own loop-current detector, which may read across a slab face) or a direction-vector
+    point source (whose six additions may fall on two ranks): fields, detector readings,
+    the source's voltage records."""
+    monkeypatch.setenv("FUZZ_EXTRAS", "1")
+    _fuzz(3, 7000, 60, True, tmp_path)
+
+
+@pytest.mark.gpu
 def test_random_scenes_on_slabs_gpu(tmp_path):
     """The same on the HIP engine, three ranks sharing the GPU."""
     _fuzz(3, 400, 90, True, tmp_path)

@@ -7,7 +7,8 @@ plane ranges, the cross-rank x-periodic copy); cpu: the slab host logic over the
 engine of tests/slab_support.py.  The gathered E and H and every detector's readings
 (each rank's part, joined in rank order) must equal the oracle's single-grid result to
 1e-12 (float64).  Scenes whose x-PML is thicker than the thinnest slab are left out (refused
-at registration), and so are those with a SoftArbitraryPointSource (refused as well).
+at registration); the CPU runs also leave out those with a SoftArbitraryPointSource, which
+the oracle slab engine does not have.
 FUZZ_BIG=1: extents of 40-128 cells; FUZZ_CROWDED=1: many objects, sources and detectors;
 FUZZ_EXTRAS=1: direction-vector point sources in some scenes.
 """
@@ -25,21 +26,27 @@ import fuzz_scenes  # noqa: E402
 import scenes  # noqa: E402
 import slab_support  # noqa: E402
 
-BIG = os.environ.get("FUZZ_BIG") == "1"     # extents of 40-128 cells (planes for the fast kernels)
-CROWDED = os.environ.get("FUZZ_CROWDED") == "1"
-EXTRAS = os.environ.get("FUZZ_EXTRAS") == "1"   # direction-vector point sources too
-FLOATS = os.environ.get("FUZZ_FLOATS") == "1"   # some keys, extents and periods in metres / seconds
+# FUZZ_BIG=1     # extents of 40-128 cells (planes for the fast kernels)
+# FUZZ_CROWDED=1
+# FUZZ_EXTRAS=1   # direction-vector point sources too
+# FUZZ_FLOATS=1   # some keys, extents and periods in metres / seconds
 DETECTORS = {"linedet": ("E", "H"), "blockdet": ("E", "H"), "currentdet": ("I",)}
 
 
-SUBSTRATE = os.environ.get("FUZZ_SUBSTRATE") == "1"   # 2-D scenes with an energy-modulated object (GPU only)
+# FUZZ_SUBSTRATE=1   # 2-D scenes with an energy-modulated object (GPU only)
+
+
+def flag(name):
+    """Scene options come from the environment (read at every call, so that a test can set
+    them for itself and the ranks it spawns)."""
+    return os.environ.get("FUZZ_" + name) == "1"
 
 
 def make_scene(seed, crowded=None):
-    if SUBSTRATE:
+    if flag("SUBSTRATE"):
         return fuzz_scenes.random_substrate_scene(seed)
-    return fuzz_scenes.random_scene(seed, big=BIG, extras=EXTRAS, floats=FLOATS,
-                                    crowded=CROWDED if crowded is None else crowded)
+    return fuzz_scenes.random_scene(seed, big=flag("BIG"), extras=flag("EXTRAS"), floats=flag("FLOATS"),
+                                    crowded=flag("CROWDED") if crowded is None else crowded)
 
 
 def stacked(readings):
@@ -48,14 +55,14 @@ def stacked(readings):
                      for r in readings], dtype=np.float64)
 
 
-def usable(scene, world):
+def usable(scene, world, on_gpu=True):
     nx = scene["grid"]["shape"][0]
     if nx < world:
         return False
     thinnest = nx // world
     for item in scene["items"]:
         kind, key = item[0], item[1]
-        if kind == "soft":     # SoftArbitraryPointSource refuses slab grids
+        if kind == "soft" and not on_gpu:   # not in the oracle slab engine of the CPU runs
             return False
         if kind == "pml" and isinstance(key[0], slice) and (key[0].start, key[0].stop) != (None, None):
             t = key[0].stop if key[0].stop is not None else -key[0].start
@@ -106,6 +113,12 @@ def worker(rank, world, port, seeds, on_gpu, out, crowded=None):
             for n, item in enumerate(made):
                 for attr in DETECTORS.get(item[0], ()):
                     mine[f"det{n}_{attr}"] = stacked(getattr(item[1], attr))
+                if item[0] == "soft":   # the rank that holds the cell has the two voltage records
+                    mine[f"det{n}_I"] = stacked(item[1].current_detector.I)
+                    for attr in ("input_voltage", "source_voltage"):
+                        got = stacked(getattr(item[1], attr))
+                        mine[f"det{n}_{attr}"] = (got.reshape(len(got), -1) if len(got)
+                                                   else np.zeros((scene["steps"], 0)))
             parts = [None] * world
             dist.all_gather_object(parts, mine)
             if rank == 0:
@@ -130,11 +143,16 @@ def oracle_results(scene):
     for n, item in enumerate(omade):
         for attr in DETECTORS.get(made[n][0], ()):
             want[f"det{n}_{attr}"] = stacked(getattr(item[1], attr))
+        if made[n][0] == "soft":
+            want[f"det{n}_I"] = stacked(item[1].current_detector.I)
+            for attr in ("input_voltage", "source_voltage"):
+                got = np.array(getattr(item[1], attr), dtype=np.float64)
+                want[f"det{n}_{attr}"] = got.reshape(len(got), -1)
     return want
 
 
 def run(world, first, count, on_gpu, out, crowded=None):
-    seeds = [s for s in range(first, first + count) if usable(make_scene(s, crowded), world)]
+    seeds = [s for s in range(first, first + count) if usable(make_scene(s, crowded), world, on_gpu)]
     mp.spawn(worker, args=(world, slab_support.free_port(), seeds, on_gpu, out, crowded), nprocs=world, join=True)
     z = np.load(out)
     bad = {}
