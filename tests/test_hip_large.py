@@ -198,6 +198,36 @@ def test_offsets_beyond_2_to_31_elements():
     assert torch.equal(fields[0][0], fields[1][0]) and torch.equal(fields[0][1], fields[1][1])
 
 
+@pytest.mark.parametrize("shape", [(70001, 3, 5), (2, 262201, 17), (3, 2, 300007), (66000, 70, 1)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_extreme_aspect_ratios_against_oracle(shape):
+    """One extent beyond what a launch grid dimension holds (65535 planes, 65535 row quads)
+    or far beyond the others: the library has to pick a kernel and a grid that cover such a
+    shape.  PMLs on the long axis, an object, sources near both ends, 6 steps, float64
+    against the oracle."""
+    fdtd.set_backend("hip.float64")
+    long = int(np.argmax(shape))
+    g, o = fdtd.Grid(shape), orc.OracleGrid(shape)
+    for side, key in (("low", slice(0, 6)), ("high", slice(-6, None))):
+        loc = [slice(None)] * 3
+        loc[long] = key
+        g[tuple(loc)] = fdtd.PML()
+        o.add_pml(long, side, 6)
+    box = [(0, min(2, n)) for n in shape]
+    box[long] = (shape[long] - 40, shape[long] - 9)
+    g[tuple(slice(a, b) for a, b in box)] = fdtd.Object(permittivity=2.0)
+    o.add_object(tuple(v for ab in box for v in ab), 2.0)
+    for pos in (8, shape[long] // 2, shape[long] - 8):
+        cell = [n // 2 for n in shape]
+        cell[long] = pos
+        g[tuple(cell)] = fdtd.PointSource(period=7)
+        o.add_point_source(tuple(cell), period=7)
+    g.run(6, progress_bar=False)
+    o.run(6)
+    assert np.abs(o.E).max() > 0
+    assert rel_l2(host(g.E), o.E) <= 1e-12 and rel_l2(host(g.H), o.H) <= 1e-12
+
+
 def test_large_grid_kernels_on_small_ragged_shapes():
     """FDTDHIP_FORCE=1 makes the library use its large-grid kernels whatever the plane
     size: every golden scene (2-D, 1-D, ragged extents, all boundary orders) must still
