@@ -139,11 +139,11 @@ def test_random_larger_scenes_match_oracle():
     assert not bad, f"scenes above 1e-12: {bad}"
 
 
-def adjoint_mismatch(seed):
+def adjoint_mismatch(seed, big=False, scene=None):
     """Relative mismatch between the adjoint's directional derivative and central differences
-    for a random scene with a learnable anisotropic object added (float64)."""
+    for a random scene (or the one given) with a learnable anisotropic object added (float64)."""
     fdtd.set_backend("hip.float64")
-    scene = fuzz_scenes.random_scene(seed)
+    scene = scene or fuzz_scenes.random_scene(seed, big=big)
     rs = np.random.RandomState(seed + 77)
     shape = scene["grid"]["shape"]
     box = fuzz_scenes._box(rs, shape, max_frac=0.5)
@@ -200,6 +200,26 @@ def test_random_scenes_adjoint_against_finite_differences():
         err, analytic, numeric, scene = adjoint_mismatch(seed)
         if not err <= 1e-5:
             bad[seed] = (err, analytic, numeric, scene)
+    assert not bad, bad
+
+
+def test_larger_scenes_adjoint_against_finite_differences():
+    """The same on extents of 40-128 cells, where the adjoint kernels take the row lane
+    mapping and the unpaired launches, and on a grid of 70001 planes of 3 x 5 cells."""
+    bad = {}
+    for seed in range(1200, 1210):
+        err, analytic, numeric, scene = adjoint_mismatch(seed, big=True)
+        if not err <= 1e-5:
+            bad[seed] = (err, analytic, numeric, scene)
+    S = slice
+    thin = dict(grid=dict(shape=(70001, 3, 5)), steps=7, items=[
+        ("pml", (S(0, 5), S(None), S(None)), {}), ("pml", (S(-5, None), S(None), S(None)), {}),
+        ("periodic", (S(None), 0, S(None)), {}),
+        ("absorbing", (S(69000, 69990), S(0, 2), S(1, 4)), dict(permittivity=1.7, conductivity=0.3)),
+        ("point", (69980, 1, 2), dict(period=6)), ("point", (9, 2, 1), dict(period=8))])
+    err, analytic, numeric, _ = adjoint_mismatch(1, scene=thin)
+    if not err <= 1e-5:
+        bad["thin"] = (err, analytic, numeric)
     assert not bad, bad
 
 
