@@ -263,6 +263,16 @@ def test_scenes_with_feedback_sources_on_slabs_gpu(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_random_scenes_on_slabs_float32_gpu(tmp_path, monkeypatch):
+    """The float32 engine on three slabs (the precision of the multi-GPU benchmark) against
+    the float64 oracle at 1e-5, on small scenes and on extents of 40-128 cells."""
+    monkeypatch.setenv("FUZZ_FLOAT32", "1")
+    _fuzz(3, 400, 60, True, tmp_path)
+    monkeypatch.setenv("FUZZ_BIG", "1")
+    _fuzz(2, 1000, 12, True, tmp_path)
+
+
+@pytest.mark.gpu
 def test_random_scenes_on_slabs_gpu(tmp_path):
     """The same on the HIP engine, three ranks sharing the GPU."""
     _fuzz(3, 400, 90, True, tmp_path)

@@ -10,7 +10,8 @@ engine of tests/slab_support.py.  The gathered E and H and every detector's read
 at registration); the CPU runs also leave out those with a SoftArbitraryPointSource, which
 the oracle slab engine does not have.
 FUZZ_BIG=1: extents of 40-128 cells; FUZZ_CROWDED=1: many objects, sources and detectors;
-FUZZ_EXTRAS=1: direction-vector point sources in some scenes.
+FUZZ_EXTRAS=1: direction-vector point sources and soft sources in some scenes;
+FUZZ_FLOAT32=1: the engine in float32 (GPU runs), tolerance 1e-5.
 """
 import os
 import sys
@@ -89,7 +90,7 @@ def worker(rank, world, port, seeds, on_gpu, out, crowded=None):
     slab_support.init_gloo(rank, world, port)
     try:
         if on_gpu:
-            fdtd.set_backend("hip.float64", device=0)
+            fdtd.set_backend("hip.float32" if flag("FLOAT32") else "hip.float64", device=0)
             factory = None
         else:
             fdtd.set_backend("hip.float64", device="host-staging")
@@ -165,7 +166,10 @@ def run(world, first, count, on_gpu, out, crowded=None):
                 continue
             n = np.linalg.norm(want.ravel())
             err = np.linalg.norm((got - want).ravel()) / (n if n > 0 else 1.0)
-            if not err <= 1e-12:
+            # float32 (GPU runs, FUZZ_FLOAT32=1): 1e-5, loop currents 1e-3 -- differences of
+            # nearly equal field values, as in tests/test_fuzz.py
+            tol = 1e-12 if not flag("FLOAT32") else (1e-3 if name.endswith("_I") else 1e-5)
+            if not err <= tol:
                 bad.setdefault(seed, {})[name] = err
     return seeds, bad
 
@@ -178,5 +182,5 @@ if __name__ == "__main__":
         print(f"seed {seed}: {errs}\n   {make_scene(seed)}")
     print(f"x{world} {'gpu' if on_gpu else 'cpu'}: {len(seeds)} scenes "
           f"({sum(crosses(make_scene(s), world) for s in seeds)} with a current loop across slabs), "
-          f"{len(bad)} above 1e-12")
+          f"{len(bad)} above {'1e-5' if flag('FLOAT32') else '1e-12'}")
     sys.exit(1 if bad else 0)
