@@ -330,24 +330,29 @@ def test_random_operation_sequences_match_oracle():
     assert not bad, bad
 
 
-def training_loop_mismatch(seed):
+def training_loop_mismatch(seed, substrate=False):
     """A grid re-used over optimisation iterations (reset, differentiable run of varying
     length, backward, in-place parameter update, sometimes a no-grad run in between) against
     a freshly built grid per iteration: losses and gradients must be bitwise equal.  Scenes
-    without PML, whose memory variables ``reset()`` keeps (reference fdtd/grid.py:327-333)."""
+    without PML, whose memory variables ``reset()`` keeps (reference fdtd/grid.py:327-333).
+    substrate: the learnable object is an energy-modulated one in a 2-D scene, and the
+    weights of its modifier's convolution learn along with its tensor."""
     fdtd.set_backend("hip.float64")
     rs = np.random.RandomState(seed + 4242)
-    scene = fuzz_scenes.random_scene(seed)
+    scene = fuzz_scenes.random_substrate_scene(seed) if substrate else fuzz_scenes.random_scene(seed)
     scene["items"] = [it for it in scene["items"] if it[0] != "pml"]
     shape = scene["grid"]["shape"]
-    box = fuzz_scenes._box(rs, shape, max_frac=0.5)
-    scene["items"].append(("learnable", box, dict(permittivity=float(1.5 + rs.rand())),
-                           dict(offdiag_seed=int(rs.randint(1 << 30)), offdiag_scale=0.03)))
+    if not substrate:
+        box = fuzz_scenes._box(rs, shape, max_frac=0.5)
+        scene["items"].append(("learnable", box, dict(permittivity=float(1.5 + rs.rand())),
+                               dict(offdiag_seed=int(rs.randint(1 << 30)), offdiag_scale=0.03)))
     if not any(it[0] in ("point", "line", "plane") for it in scene["items"]):
         scene["items"].append(("point", tuple(n // 2 for n in shape), dict(period=9)))
 
-    def learnable(made):
-        return [t for k, t, _, _ in made if k == "learnable"][0]
+    def parameters(made):
+        obj = [t for k, t, _, _ in made if k in ("learnable", "substrate")][0]
+        extra = [obj.nonlin_conv.weight, obj.nonlin_conv.bias] if substrate else []
+        return [obj.inverse_permittivity] + extra
 
     def loss_of(grid):
         w = np.random.RandomState(seed + 5)
@@ -355,7 +360,7 @@ def training_loop_mismatch(seed):
         return (WE * grid.E ** 2).sum() + (WH * grid.H ** 2).sum()
 
     grid, made = scenes.build_api(scene, fdtd)
-    obj = learnable(made)
+    params = parameters(made)
     bad = {}
     for it in range(int(rs.randint(2, 5))):
         n = int(rs.randint(2, 14))
@@ -368,20 +373,23 @@ def training_loop_mismatch(seed):
         loss.backward()
         # the same iteration on a fresh grid with the same parameter values
         fresh, fmade = scenes.build_api(scene, fdtd)
-        fobj = learnable(fmade)
+        fparams = parameters(fmade)
         with torch.no_grad():
-            fobj.inverse_permittivity.copy_(obj.inverse_permittivity)
+            for a, b in zip(fparams, params):
+                a.copy_(b)
         fresh.run(n, progress_bar=False)
         floss = loss_of(fresh)
         floss.backward()
         if loss.item() != floss.item():
             bad[f"loss{it}"] = (loss.item(), floss.item())
-        if not torch.equal(obj.inverse_permittivity.grad, fobj.inverse_permittivity.grad):
-            bad[f"grad{it}"] = float((obj.inverse_permittivity.grad - fobj.inverse_permittivity.grad).abs().max())
+        for k, (a, b) in enumerate(zip(params, fparams)):
+            if a.grad is None or b.grad is None or not torch.equal(a.grad, b.grad):
+                bad[f"grad{it}_{k}"] = "missing" if a.grad is None or b.grad is None else float((a.grad - b.grad).abs().max())
         with torch.no_grad():
-            obj.inverse_permittivity -= 0.05 * obj.inverse_permittivity.grad / (
-                obj.inverse_permittivity.grad.abs().max() + 1e-30)
-            obj.inverse_permittivity.grad = None
+            for a in params:
+                if a.grad is not None:
+                    a -= 0.05 * a.abs().max() * a.grad / (a.grad.abs().max() + 1e-30)
+                    a.grad = None
     return bad
 
 
@@ -391,5 +399,9 @@ def test_reused_grid_training_loop_equals_fresh_grids():
         out = training_loop_mismatch(seed)
         if out:
             bad[seed] = out
+    for seed in range(20):
+        out = training_loop_mismatch(seed, substrate=True)
+        if out:
+            bad[f"substrate{seed}"] = out
     assert not bad, bad
 
