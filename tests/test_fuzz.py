@@ -226,7 +226,8 @@ def test_larger_scenes_adjoint_against_finite_differences():
 def operation_sequence_mismatch(seed):
     """A random scene driven by a random sequence of user operations between runs -- writes
     into the material arrays (in place and by re-binding), into the fields, into an object's
-    tensor, components registered after steps were taken, runs through ``run`` and through
+    tensor, components and boundaries registered after steps were taken, fields re-bound to
+    new arrays, runs through ``run`` and through
     the half-step entry points -- mirrored on the oracle.  Exercises everything the host
     layer caches between runs (plan signature, bound pointers, constant-material scan)."""
     from oracle import yee_numpy as orc  # noqa: F401  (the oracle is the checker here)
@@ -244,9 +245,21 @@ def operation_sequence_mismatch(seed):
     def box():
         return tuple(slice(a.start, a.stop) for a in fuzz_scenes._box(rs, shape))
 
+    # faces that already carry a boundary: (axis, "low" / "high")
+    taken = set()
+    for item in scene["items"]:
+        if item[0] in ("pml", "periodic"):
+            axis = [a for a in range(3) if item[1][a] != slice(None)][0]
+            k = item[1][axis]
+            if item[0] == "periodic":
+                taken |= {(axis, "low"), (axis, "high")}
+            else:
+                taken.add((axis, "low" if k.start in (0, None) and k.stop is not None else "high"))
+
     for _ in range(int(rs.randint(4, 10))):
         op = rs.choice(["run", "halfsteps", "eps_inplace", "mu_inplace", "eps_rebind", "field", "object",
-                        "add_source", "add_detector", "add_object", "reset"])
+                        "add_source", "add_detector", "add_object", "reset", "add_boundary",
+                        "field_rebind"])
         log.append(str(op))
         if op == "run":
             n = int(rs.randint(1, 7))
@@ -303,6 +316,29 @@ def operation_sequence_mismatch(seed):
             og.E[...] = 0.0
             og.H[...] = 0.0
             og.time_steps_passed = 0
+        elif op == "add_boundary":
+            # a boundary registered after steps were taken: it joins the end of the list
+            free = [(a, side) for a in range(3) for side in ("low", "high")
+                    if (a, side) not in taken and shape[a] >= 4]
+            if free:
+                axis, side = free[int(rs.randint(len(free)))]
+                key = [slice(None)] * 3
+                if (axis, "low") not in taken and (axis, "high") not in taken and rs.rand() < 0.3:
+                    key[axis] = 0
+                    grid[tuple(key)] = fdtd.PeriodicBoundary()
+                    og.add_periodic(axis)
+                    taken |= {(axis, "low"), (axis, "high")}
+                else:
+                    t = int(rs.randint(1, max(2, min(6, shape[axis] // 2))))
+                    key[axis] = slice(0, t) if side == "low" else slice(-t, None)
+                    grid[tuple(key)] = fdtd.PML()
+                    og.add_pml(axis, side, t)
+                    taken.add((axis, side))
+        elif op == "field_rebind":
+            name = str(rs.choice(["E", "H"]))
+            vals = 1e-2 * rs.randn(*shape, 3)
+            setattr(grid, name, fdtd.backend.array(vals))
+            setattr(og, name, vals.copy())
         elif op == "add_object":
             b = box()
             eps = float(1.5 + rs.rand())
