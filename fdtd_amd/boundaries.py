@@ -187,14 +187,15 @@ class PML(Boundary):
         reference's expressions (fdtd/boundaries.py:384-396 and 491-522)."""
         t = self.thickness = int(thickness)
         g = self.grid
-        n = g.shape[self.axis]
-        # an x-face PML exists only on the slab that holds that face of the simulation
+        # an x-face PML exists only on the slab that holds that face of the simulation; every
+        # rank checks it against that slab, so that all of them refuse it together
+        n = g.shape[self.axis] if self.axis else g._planes_of_end_slab(self.side)
+        if t > n:
+            raise IndexError("PML thicker than the grid (or than the x-slab that holds it)")
         self._active = self.axis != 0 or (g._is_first_slab if self.side == "low" else g._is_last_slab)
         if not self._active:
             self._psiE = self._psiH = None
             return
-        if t > n:
-            raise IndexError("PML thicker than the grid (or than the x-slab that holds it)")
         span = slice(None, t) if self.side == "low" else slice(-t, None)
         loc = [slice(None)] * 3
         loc[self.axis] = span

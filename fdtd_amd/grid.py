@@ -114,6 +114,11 @@ class Grid:
         hi = min(stop - self.x_offset, self.Nx)
         return lo, max(lo, hi)
 
+    def _planes_of_end_slab(self, side):
+        """Number of x planes of the slab that holds the "low" / "high" x face of the
+        simulation (this grid itself unless it is one slab of several)."""
+        return self.Nx
+
     def _local_x(self, xg):
         """Global plane index -> local index, or None if another slab owns it."""
         xl = xg - self.x_offset

@@ -127,6 +127,10 @@ class SlabGrid(Grid):
         self.Nx = base + (1 if r < extra else 0)
         self.x_offset = r * base + min(r, extra)
 
+    def _planes_of_end_slab(self, side):
+        base, extra = divmod(self.Nx_global, self._world)
+        return base + (1 if side == "low" and extra > 0 else 0)
+
     def _global_rank(self, r):
         return r if self._group is None else dist.get_global_rank(self._group, r)
 

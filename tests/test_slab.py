@@ -221,6 +221,41 @@ def test_partition_arithmetic():
         Fake(3, 4, 0)
 
 
+def _refusal_worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    import fdtd_amd as fdtd
+    from fdtd_amd.parallel import SlabGrid
+
+    slab_support.init_gloo(rank, world, port)
+    try:
+        fdtd.set_backend("hip.float64", device="host-staging")
+        grid = SlabGrid((11, 8, 1), engine_factory=slab_support.OracleSlabEngine)   # 6 + 5 planes
+        grid[0:6, :, :] = fdtd.PML()              # fits rank 0's six planes
+        seen = "accepted"
+        try:
+            grid[-6:, :, :] = fdtd.PML()          # thicker than rank 1's five
+        except IndexError as e:
+            seen = f"IndexError: {e}"
+        everyone = [None] * world
+        dist.all_gather_object(everyone, seen)
+        if rank == 0:
+            with open(out, "w") as f:
+                f.write("\n".join(everyone))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_x_pml_thicker_than_its_slab_is_refused_on_every_rank(tmp_path):
+    """The slab at that end of the simulation cannot hold the PML: every rank raises, also
+    those that would not hold any of it -- a refusal on one rank only would leave the others
+    waiting for its planes at the first step."""
+    out = str(tmp_path / "refusal.txt")
+    mp.spawn(_refusal_worker, args=(2, slab_support.free_port(), out), nprocs=2, join=True)
+    lines = open(out).read().splitlines()
+    assert len(lines) == 2 and all(line.startswith("IndexError: PML thicker") for line in lines), lines
+
+
 def _fuzz(world, first, count, on_gpu, tmp_path, crowded=False):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_slab
