@@ -298,6 +298,22 @@ SLAB_SCENES = {
         ],
         steps=36,
     ),
+    # five planes: on three ranks the last slab is a single plane (its E update reads the ghost
+    # plane below, its H update the ghost plane above, in the same plane), on 2 ranks 3 + 2
+    "slab_one_plane": dict(
+        grid=dict(shape=(5, 12, 9)),
+        items=[
+            ("pml",      (S(None), S(0, 3), S(None)), {}),
+            ("pml",      (S(-1, None), S(None), S(None)), {}),
+            ("periodic", (S(None), S(None), 0), {}),
+            ("object",   (S(0, 5), S(4, 9), S(2, 6)), dict(permittivity=2.0)),
+            ("anisotropic", (S(3, 5), S(6, 11), S(5, 8)), dict(permittivity=1.7), dict(offdiag_seed=4, offdiag_scale=0.05)),
+            ("point",    (4, 6, 4), dict(period=8)),
+            ("point",    (2, 3, 7), dict(period=11, amplitude=0.5)),
+            ("linedet",  (S(0, 5), 7, 3), {}),
+        ],
+        steps=16,
+    ),
     "slab_2d": dict(
         grid=dict(shape=(31, 17, 1)),
         items=[

@@ -110,6 +110,18 @@ def test_slabs_equal_single_grid_gpu(scene_name, tmp_path):
     _check(scene_name, 2, True, tmp_path)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [3, 5])
+def test_one_plane_slabs_gpu(world, tmp_path):
+    """Five planes on three ranks (2 + 2 + 1) and on five (one plane each: every launch
+    covers the plane that waits for a ghost, the interior launch is empty)."""
+    _check("slab_one_plane", world, True, tmp_path)
+
+
+def test_one_plane_per_rank_cpu(tmp_path):
+    _check("slab_one_plane", 5, False, tmp_path)
+
+
 def _local_loss(scene, grid):
     """This rank's part of scenes.adjoint_loss (the parts add up to it)."""
     spec = scene["loss"]
