@@ -26,9 +26,10 @@ def _box(rs, shape, max_frac=0.6):
     return tuple(key)
 
 
-def random_scene(seed, big=False, extras=False, floats=False, crowded=False):
+def random_scene(seed, big=False, extras=False, floats=False, crowded=False, thin_x=0):
     """crowded: 8-24 objects, 9-14 sources and 9-13 detectors instead of up to 3 / 3 / 2 (more
-    than any fixed-size batch or table inside the engine holds)."""
+    than any fixed-size batch or table inside the engine holds).  thin_x = n: n to n + 2 planes
+    along x (slabs of one or two planes when split over n ranks)."""
     rs = np.random.RandomState(seed)
     dims = rs.choice([1, 2, 3], p=[0.1, 0.4, 0.5])
     lo, hi = (9, 30) if not big else (40, 90)
@@ -36,6 +37,8 @@ def random_scene(seed, big=False, extras=False, floats=False, crowded=False):
     flat = list(rs.permutation(3)[: 3 - dims])
     for ax in flat:
         ext[ax] = 1
+    if thin_x:
+        ext[0] = thin_x + seed % 3
     if big and dims == 3:
         ext[2] = int(rs.choice([64, 65, 96, 128, 70]))
     shape = tuple(ext)

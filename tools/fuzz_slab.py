@@ -11,7 +11,8 @@ at registration); the CPU runs also leave out those with a SoftArbitraryPointSou
 the oracle slab engine does not have.
 FUZZ_BIG=1: extents of 40-128 cells; FUZZ_CROWDED=1: many objects, sources and detectors;
 FUZZ_EXTRAS=1: direction-vector point sources and soft sources in some scenes;
-FUZZ_FLOAT32=1: the engine in float32 (GPU runs), tolerance 1e-5.
+FUZZ_FLOAT32=1: the engine in float32 (GPU runs), tolerance 1e-5; FUZZ_THIN_X=n: n to n + 2
+planes along x (slabs of one or two planes on n ranks).
 """
 import os
 import sys
@@ -47,6 +48,7 @@ def make_scene(seed, crowded=None):
     if flag("SUBSTRATE"):
         return fuzz_scenes.random_substrate_scene(seed)
     return fuzz_scenes.random_scene(seed, big=flag("BIG"), extras=flag("EXTRAS"), floats=flag("FLOATS"),
+                                    thin_x=int(os.environ.get("FUZZ_THIN_X", "0")),
                                     crowded=flag("CROWDED") if crowded is None else crowded)
 
 
@@ -61,6 +63,8 @@ def usable(scene, world, on_gpu=True):
     if nx < world:
         return False
     thinnest = nx // world
+    if not on_gpu and thinnest == 1 and scene["grid"]["shape"][1] == scene["grid"]["shape"][2] == 1:
+        return False   # a slab of one cell: the oracle grid of the CPU runs has no such shape
     for item in scene["items"]:
         kind, key = item[0], item[1]
         if kind == "soft" and not on_gpu:   # not in the oracle slab engine of the CPU runs

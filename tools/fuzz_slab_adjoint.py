@@ -27,7 +27,8 @@ import slab_support  # noqa: E402
 
 
 def scene_for(seed):
-    scene = fuzz_scenes.random_scene(seed)
+    # FUZZ_THIN_X=n: n to n + 2 planes along x (one- and two-plane slabs on n ranks)
+    scene = fuzz_scenes.random_scene(seed, thin_x=int(os.environ.get("FUZZ_THIN_X", "0")))
     rs = np.random.RandomState(seed + 77)
     box = fuzz_scenes._box(rs, scene["grid"]["shape"], max_frac=0.6)
     scene["items"].append(("learnable", box, dict(permittivity=float(1.5 + rs.rand())),
