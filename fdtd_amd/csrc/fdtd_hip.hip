@@ -795,6 +795,13 @@ int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArg
   fill_core<T>(p, boxes);
   for (int n = 0; n < 6; ++n) { a.hull[n] = boxes.hull[n]; a.core[n] = boxes.core[n]; }
   a.rot_shift = boxes.rot_shift;
+  // (x-slabs exchange planes of `work` between ranks: every cell's entry has to exist)
+  static const bool direct_allowed = [] {
+    const char* e = getenv("FDTDHIP_ADJ_DIRECT");
+    return !e || atoi(e) != 0;
+  }();
+  a.direct = direct_allowed && a.mat_const && !p->H_below && !p->E_above &&
+                     (adjoint_rows(p) || p->cells() > (int64_t)(1 << 19)) ? 1 : 0;
   return 0;
 }
 

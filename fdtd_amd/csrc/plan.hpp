@@ -102,6 +102,8 @@ struct AdjArgs {
   int hull[6];         // box containing every object
   int core[6];         // box no PML slab reaches
   int rot_shift;       // row mapping: z-segment rotation period (as in BulkArgs)
+  int direct;          // cells far from every PML and object skip pass 1, and pass 2 derives
+                       // their difference adjoints from lamF itself
 };
 
 }  // namespace fdtdhip

@@ -107,6 +107,95 @@ __device__ __forceinline__ bool adj_any_obj(const AdjArgs<T>& a, int i, int j, i
   return a.nobj > 0 && __any(near);
 }
 
+// "Plain" cells: outside every PML slab and outside the hull of the objects, with the
+// material a proven constant.  There pass 1 is a fixed linear map of the cell's own lamF
+// (no memory variable, no object, lamF left as it is), so pass 2 can evaluate it for the
+// cell and the three neighbours it gathers from instead of reading `work`: 9 values per
+// cell and half step through memory instead of 21.  The choice is made per cell: pass 2
+// takes the direct form where the cell and the neighbours it reaches are plain, and pass 1
+// leaves a cell out when every cell that could read its entry -- itself and its six
+// neighbours' gathers, all of which reach at most one cell further -- takes the direct
+// form, i.e. when the 3 x 3 x 3 block around it is plain.  Inclusive cell ranges, clamped
+// to the grid.
+template <typename T>
+__device__ __forceinline__ bool adj_box_plain(const AdjArgs<T>& a, int i0, int i1, int j0, int j1,
+                                              int k0, int k1) {
+  i0 = max(i0, 0); j0 = max(j0, 0); k0 = max(k0, 0);
+  i1 = min(i1, a.nx - 1); j1 = min(j1, a.ny - 1); k1 = min(k1, a.nz - 1);
+  const bool in_core = i0 >= a.core[0] && i1 < a.core[1] && j0 >= a.core[2] && j1 < a.core[3] &&
+                       k0 >= a.core[4] && k1 < a.core[5];
+  const bool meets_hull = a.nobj > 0 && i1 >= a.hull[0] && i0 < a.hull[1] && j1 >= a.hull[2] &&
+                          j0 < a.hull[3] && k1 >= a.hull[4] && k0 < a.hull[5];
+  return in_core && !meets_hull;
+}
+
+// Pass 1 has nothing to leave behind for this cell.
+template <typename T>
+__device__ __forceinline__ bool adj_cells_skippable(const AdjArgs<T>& a, int i, int j, int k) {
+  return a.direct && adj_box_plain(a, i - 1, i + 1, j - 1, j + 1, k - 1, k + 1);
+}
+
+// The difference adjoints of a plain cell from its lamF, as pass 1 would have stored them
+// (edge rule included: differences the forward pass dropped carry no adjoint).
+template <typename T, bool PHASE_E>
+__device__ __forceinline__ void adj_plain_G(const AdjArgs<T>& a, const T* lam, int i, int j, int k,
+                                            T G[6]) {
+  T g[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const T v = (a.sc * a.bg[c]) * lam[c];
+    g[c] = PHASE_E ? v : -v;
+  }
+  G[WY_Z] = g[0]; G[WZ_Y] = -g[0];
+  G[WZ_X] = g[1]; G[WX_Z] = -g[1];
+  G[WX_Y] = g[2]; G[WY_X] = -g[2];
+  if (PHASE_E) {
+    if (i == 0 && !a.open_lo) G[WX_Y] = G[WX_Z] = 0;
+    if (j == 0) G[WY_X] = G[WY_Z] = 0;
+    if (k == 0) G[WZ_X] = G[WZ_Y] = 0;
+  } else {
+    if (i == a.nx - 1 && !a.open_hi) G[WX_Y] = G[WX_Z] = 0;
+    if (j == a.ny - 1) G[WY_X] = G[WY_Z] = 0;
+    if (k == a.nz - 1) G[WZ_X] = G[WZ_Y] = 0;
+  }
+}
+
+// Pass 2 of a plain cell with plain neighbours: the same sums as
+// adj_gather_cell, the difference adjoints taken from lamF (a.lamF is not written by
+// anything while the two passes of a half step run, outside absorbing objects).
+template <typename T, bool PHASE_E>
+__device__ __forceinline__ void adj_gather_direct(const AdjArgs<T>& a, int i, int j, int k, T add[3]) {
+  const int64_t sy = 3 * (int64_t)a.nz, sx = sy * a.ny;
+  const T* l = a.lamF + (((int64_t)i * a.ny + j) * a.nz + k) * 3;
+  const int s = PHASE_E ? 1 : -1;
+  const bool ox = PHASE_E ? i < a.nx - 1 : i > 0;
+  const bool oy = PHASE_E ? j < a.ny - 1 : j > 0;
+  const bool oz = PHASE_E ? k < a.nz - 1 : k > 0;
+  // all loads first (a missing neighbour reads the cell itself and is discarded)
+  const T* lx = ox ? l + s * sx : l;
+  const T* ly = oy ? l + s * sy : l;
+  const T* lz = oz ? l + s * 3 : l;
+  const T own[3] = {l[0], l[1], l[2]};
+  const T vx[3] = {lx[0], lx[1], lx[2]};
+  const T vy[3] = {ly[0], ly[1], ly[2]};
+  const T vz[3] = {lz[0], lz[1], lz[2]};
+  T w[6], wx[6], wy[6], wz[6];
+  adj_plain_G<T, PHASE_E>(a, own, i, j, k, w);
+  adj_plain_G<T, PHASE_E>(a, vx, i + s, j, k, wx);
+  adj_plain_G<T, PHASE_E>(a, vy, i, j + s, k, wy);
+  adj_plain_G<T, PHASE_E>(a, vz, i, j, k + s, wz);
+  const T zero = T(0);
+  if (PHASE_E) {
+    add[0] = (w[WY_X] - (oy ? wy[WY_X] : zero)) + (w[WZ_X] - (oz ? wz[WZ_X] : zero));
+    add[1] = (w[WX_Y] - (ox ? wx[WX_Y] : zero)) + (w[WZ_Y] - (oz ? wz[WZ_Y] : zero));
+    add[2] = (w[WX_Z] - (ox ? wx[WX_Z] : zero)) + (w[WY_Z] - (oy ? wy[WY_Z] : zero));
+  } else {
+    add[0] = ((oy ? wy[WY_X] : zero) - w[WY_X]) + ((oz ? wz[WZ_X] : zero) - w[WZ_X]);
+    add[1] = ((ox ? wx[WX_Y] : zero) - w[WX_Y]) + ((oz ? wz[WZ_Y] : zero) - w[WZ_Y]);
+    add[2] = ((ox ? wx[WX_Z] : zero) - w[WX_Z]) + ((oy ? wy[WY_Z] : zero) - w[WY_Z]);
+  }
+}
+
 // The adjoint of everything the forward E half step did at one cell after forming the six
 // neighbour differences: on return G holds the adjoints of those differences and lam the
 // adjoint of the cell's E before the half step.  store = false evaluates the cell without
@@ -215,6 +304,7 @@ template <typename T, bool ROWS>
 __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
   int i, j, k;
   if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
+  if (adj_cells_skippable(a, i, j, k)) return;
   const int64_t cell = ((int64_t)i * a.ny + j) * a.nz + k;
   const int64_t c3 = cell * 3;
   T lam[3] = {a.lamF[c3], a.lamF[c3 + 1], a.lamF[c3 + 2]};
@@ -261,6 +351,7 @@ template <typename T, bool ROWS>
 __global__ __launch_bounds__(256) void adj_H_cells(AdjArgs<T> a) {
   int i, j, k;
   if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
+  if (adj_cells_skippable(a, i, j, k)) return;
   const int64_t cell = ((int64_t)i * a.ny + j) * a.nz + k;
   const int64_t c3 = cell * 3;
   const T lam[3] = {a.lamF[c3], a.lamF[c3 + 1], a.lamF[c3 + 2]};
@@ -310,7 +401,11 @@ __global__ __launch_bounds__(256) void adj_gather(AdjArgs<T> a) {
   if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
   const int64_t cell = ((int64_t)i * a.ny + j) * a.nz + k;
   T add[3];
-  adj_gather_cell<T, PHASE_E>(a, i, j, k, add);
+  if (a.direct && (PHASE_E ? adj_box_plain(a, i, i + 1, j, j + 1, k, k + 1)
+                           : adj_box_plain(a, i - 1, i, j - 1, j, k - 1, k)))
+    adj_gather_direct<T, PHASE_E>(a, i, j, k, add);
+  else
+    adj_gather_cell<T, PHASE_E>(a, i, j, k, add);
   T* out = a.lamG + cell * 3;
   out[0] += add[0];
   out[1] += add[1];

@@ -269,6 +269,26 @@ def test_one_launch_step_forced_on_and_off(fused):
     assert " passed" in done.stdout
 
 
+def test_adjoint_without_the_direct_gather():
+    """On large grids the second adjoint pass derives the difference adjoints of cells far
+    from PMLs and objects from the field adjoint itself and the first pass leaves those cells
+    out.  FDTDHIP_ADJ_DIRECT=0 keeps the plain two-pass form everywhere (the form x-slabs
+    always use): the finite-difference checks on larger scenes must hold for it too.  Read
+    once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, FDTDHIP_ADJ_DIRECT="0")
+    done = subprocess.run(
+        [sys.executable, "-m", "pytest", os.path.join(here, "test_fuzz.py"), "-q", "-x", "-m", "gpu",
+         "-k", "larger_scenes_adjoint", "-p", "no:cacheprovider"],
+        env=env, capture_output=True, text=True, timeout=280, cwd=os.path.dirname(here))
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
+    assert " passed" in done.stdout
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_long_run_against_oracle(dtype):
     """300 steps of a 64 x 96 x 128 grid (row-mapped large-grid kernels, constant materials,

@@ -7,6 +7,7 @@ small    97x97x1 float64, periodic z, point source, learnable 40x20 box, 200 ste
 stepwise the same, advanced one step per autograd node (how reference
          cortical/autoencoder.py:108-109 drives the grid)
 large    256^3 float32, 6 PML(10), learnable 64^3 box, 40 steps forward and backward
+xlarge   the same at 512^3, 20 steps
 Prints one JSON line per workload: milliseconds per step for forward and for backward.
 """
 import argparse
@@ -30,6 +31,16 @@ def build(kind):
         g[28:68, 40:60, 0:1] = fdtd.LearnableAnisotropicObject(permittivity=2.5)
         return g, 200, (slice(40, 56), 80, slice(0, 1))
     fdtd.set_backend("hip.float32")
+    if kind == "xlarge":
+        g = fdtd.Grid((512, 512, 512))
+        for axis in range(3):
+            lo, hi = [slice(None)] * 3, [slice(None)] * 3
+            lo[axis], hi[axis] = slice(0, 10), slice(-10, None)
+            g[tuple(lo)] = fdtd.PML()
+            g[tuple(hi)] = fdtd.PML()
+        g[256, 180, 256] = fdtd.PointSource(period=20)
+        g[224:288, 224:288, 224:288] = fdtd.LearnableAnisotropicObject(permittivity=2.5)
+        return g, 20, (slice(240, 272), 330, slice(240, 272))
     g = fdtd.Grid((256, 256, 256))
     for axis in range(3):
         lo, hi = [slice(None)] * 3, [slice(None)] * 3
