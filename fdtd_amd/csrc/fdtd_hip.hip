@@ -800,7 +800,9 @@ int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArg
     const char* e = getenv("FDTDHIP_ADJ_DIRECT");
     return !e || atoi(e) != 0;
   }();
-  a.direct = direct_allowed && a.mat_const && !p->H_below && !p->E_above &&
+  // (pass 1 is then launched box by box with planes and row quads as grid dimensions)
+  a.direct = direct_allowed && a.mat_const && !p->H_below && !p->E_above && p->nx <= 65535 &&
+                     (p->ny + 3) / 4 <= 65535 &&
                      (adjoint_rows(p) || p->cells() > (int64_t)(1 << 19)) ? 1 : 0;
   return 0;
 }
@@ -874,14 +876,45 @@ int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
   AdjArgs<T> a;
   if (int rc = adjoint_args<T>(p, phaseE, lamE, lamH, work, a)) return rc;
   const dim3 block(256);
-  if (adjoint_rows(p)) {
+  const CellBox whole{0, p->nx, 0, p->ny, 0, p->nz};
+  if (a.direct) {
+    // Only cells near a PML slab or an object have a pass 1 (the kernel leaves the others
+    // out cell by cell): launch it over boxes that cover them instead of the whole grid --
+    // six slabs around the part of the PML-free core whose 3x3x3 blocks stay inside it,
+    // and the hull of the objects grown by one cell where it lies in that part.  The boxes
+    // are disjoint: pass 1 has side effects (memory-variable adjoints, object gradients).
+    int s0[3], s1[3];
+    const int n[3] = {p->nx, p->ny, p->nz};
+    for (int d = 0; d < 3; ++d) {
+      s0[d] = a.core[2 * d] + (a.core[2 * d] > 0 ? 1 : 0);
+      s1[d] = a.core[2 * d + 1] - (a.core[2 * d + 1] < n[d] ? 1 : 0);
+      s0[d] = std::min(std::max(s0[d], 0), n[d]);
+      s1[d] = std::min(std::max(s1[d], s0[d]), n[d]);
+    }
+    std::vector<CellBox> boxes = {
+        {0, s0[0], 0, n[1], 0, n[2]},           {s1[0], n[0], 0, n[1], 0, n[2]},
+        {s0[0], s1[0], 0, s0[1], 0, n[2]},      {s0[0], s1[0], s1[1], n[1], 0, n[2]},
+        {s0[0], s1[0], s0[1], s1[1], 0, s0[2]}, {s0[0], s1[0], s0[1], s1[1], s1[2], n[2]}};
+    if (a.nobj > 0)
+      boxes.push_back({std::max(a.hull[0] - 1, s0[0]), std::min(a.hull[1] + 1, s1[0]),
+                       std::max(a.hull[2] - 1, s0[1]), std::min(a.hull[3] + 1, s1[1]),
+                       std::max(a.hull[4] - 1, s0[2]), std::min(a.hull[5] + 1, s1[2])});
+    for (const CellBox& b : boxes) {
+      if (b.i1 <= b.i0 || b.j1 <= b.j0 || b.k1 <= b.k0) continue;
+      const bool thin = b.k1 - b.k0 <= 16;   // 16 cells of 4 rows per wave (box_lane_cell)
+      const dim3 grid(thin ? 1 : (b.k1 - b.k0 + 63) / 64, (b.j1 - b.j0 + (thin ? 15 : 3)) / (thin ? 16 : 4),
+                      b.i1 - b.i0);
+      if (phaseE) hipLaunchKernelGGL((adj_E_cells<T, true, true>), grid, block, 0, p->stream, a, b);
+      else hipLaunchKernelGGL((adj_H_cells<T, true, true>), grid, block, 0, p->stream, a, b);
+    }
+  } else if (adjoint_rows(p)) {
     const dim3 grid((p->nz + 63) / 64, (p->ny + 3) / 4, p->nx);
-    if (phaseE) hipLaunchKernelGGL((adj_E_cells<T, true>), grid, block, 0, p->stream, a);
-    else hipLaunchKernelGGL((adj_H_cells<T, true>), grid, block, 0, p->stream, a);
+    if (phaseE) hipLaunchKernelGGL((adj_E_cells<T, true>), grid, block, 0, p->stream, a, whole);
+    else hipLaunchKernelGGL((adj_H_cells<T, true>), grid, block, 0, p->stream, a, whole);
   } else {
     const dim3 grid(blocks_for(p->cells()));
-    if (phaseE) hipLaunchKernelGGL((adj_E_cells<T, false>), grid, block, 0, p->stream, a);
-    else hipLaunchKernelGGL((adj_H_cells<T, false>), grid, block, 0, p->stream, a);
+    if (phaseE) hipLaunchKernelGGL((adj_E_cells<T, false>), grid, block, 0, p->stream, a, whole);
+    else hipLaunchKernelGGL((adj_H_cells<T, false>), grid, block, 0, p->stream, a, whole);
   }
   HIPCHK(hipGetLastError());
   return 0;

@@ -39,6 +39,25 @@ __device__ __forceinline__ bool adj_lane_cell(const AdjArgs<T>& a, int& i, int& 
   return true;
 }
 
+// Pass 1 over a box of cells only (a launch per box, see adjoint_cells): a wave per 64-cell
+// piece of a z row of the box, 4 rows per workgroup (thin boxes: see box_lane_cell).
+struct CellBox { int i0, i1, j0, j1, k0, k1; };
+
+// A box at most 16 cells deep along z (a z-face slab) gives each wave 16 cells of 4 rows
+// instead of a quarter-filled 64-cell segment: 16 rows per workgroup.
+__device__ __forceinline__ bool box_lane_cell(const CellBox& b, int& i, int& j, int& k) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  i = b.i0 + blockIdx.z;
+  if (b.k1 - b.k0 <= 16) {
+    k = b.k0 + (lane & 15);
+    j = b.j0 + (blockIdx.y * 4 + wave) * 4 + (lane >> 4);
+  } else {
+    k = b.k0 + blockIdx.x * 64 + lane;
+    j = b.j0 + blockIdx.y * 4 + wave;
+  }
+  return k < b.k1 && j < b.j1;
+}
+
 // order of the six difference adjoints in `work`
 enum { WX_Y = 0, WX_Z = 1, WY_X = 2, WY_Z = 3, WZ_X = 4, WZ_Y = 5 };
 
@@ -300,10 +319,10 @@ __device__ __forceinline__ bool adj_E_cell(const AdjArgs<T>& a, int i, int j, in
 }
 
 // Pass 1 of the adjoint of the E half step.
-template <typename T, bool ROWS>
-__global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a) {
+template <typename T, bool ROWS, bool BOXED = false>
+__global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a, CellBox box) {
   int i, j, k;
-  if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
+  if (BOXED ? !box_lane_cell(box, i, j, k) : !adj_lane_cell<T, ROWS>(a, i, j, k)) return;
   if (adj_cells_skippable(a, i, j, k)) return;
   const int64_t cell = ((int64_t)i * a.ny + j) * a.nz + k;
   const int64_t c3 = cell * 3;
@@ -347,10 +366,10 @@ __device__ __forceinline__ void adj_H_cell(const AdjArgs<T>& a, int i, int j, in
 }
 
 // Pass 1 of the adjoint of the H half step.
-template <typename T, bool ROWS>
-__global__ __launch_bounds__(256) void adj_H_cells(AdjArgs<T> a) {
+template <typename T, bool ROWS, bool BOXED = false>
+__global__ __launch_bounds__(256) void adj_H_cells(AdjArgs<T> a, CellBox box) {
   int i, j, k;
-  if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
+  if (BOXED ? !box_lane_cell(box, i, j, k) : !adj_lane_cell<T, ROWS>(a, i, j, k)) return;
   if (adj_cells_skippable(a, i, j, k)) return;
   const int64_t cell = ((int64_t)i * a.ny + j) * a.nz + k;
   const int64_t c3 = cell * 3;
