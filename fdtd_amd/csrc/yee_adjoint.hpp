@@ -426,9 +426,17 @@ __global__ __launch_bounds__(256) void adj_gather(AdjArgs<T> a) {
   else
     adj_gather_cell<T, PHASE_E>(a, i, j, k, add);
   T* out = a.lamG + cell * 3;
-  out[0] += add[0];
-  out[1] += add[1];
-  out[2] += add[2];
+  if (ROWS && sizeof(T) == 4) {
+    // streamed once per launch: keep it out of the way of the neighbour re-reads (as the
+    // forward row kernels do for the advanced field; float64 cells gain nothing from it)
+    T o[3];
+    load3<T, true>(out, o[0], o[1], o[2]);
+    store3<T, true>(out, o[0] + add[0], o[1] + add[1], o[2] + add[2]);
+  } else {
+    out[0] += add[0];
+    out[1] += add[1];
+    out[2] += add[2];
+  }
 }
 
 // Small grids (one wave per SIMD, time = number of launches): pass 2 of one half step and
