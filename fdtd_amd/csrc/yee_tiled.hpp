@@ -109,8 +109,10 @@ __device__ __forceinline__ bool lane_cell(int x0, int ny, int nz, int rot_shift,
   return k < nz && j < ny;
 }
 
+// (8 waves per SIMD: left to itself the compiler gives the variant with PMLs and objects 68
+// vector registers, one wave fewer, which cost more than the object arithmetic itself)
 template <typename T, bool HAS_PML, bool HAS_OBJ, bool FLAT, bool NT, bool NTS>
-__global__ __launch_bounds__(256) void bulk_E_rows(BulkArgs<T> a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void bulk_E_rows(BulkArgs<T> a) {
   int i, j, k;
   if (!lane_cell<FLAT>(a.x0, a.ny, a.nz, a.rot_shift, i, j, k)) return;
   const int64_t sy = 3 * (int64_t)a.nz, sx = sy * a.ny;
