@@ -769,6 +769,17 @@ bool adjoint_rows(const fdtdhip_plan* p) {
          p->nx <= 65535 && (p->ny + 3) / 4 <= 65535;
 }
 
+// FDTDHIP_ADJ_DIRECT: 0 = never derive difference adjoints from the field adjoint (plain two
+// passes everywhere), 2 = wherever the plan allows, whatever the grid size (tests); default:
+// on grids large enough for it to matter.
+int adjoint_direct_mode() {
+  static const int mode = [] {
+    const char* e = getenv("FDTDHIP_ADJ_DIRECT");
+    return e ? atoi(e) : 1;
+  }();
+  return mode;
+}
+
 template <typename T>
 int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArgs<T>& a) {
   a.lamF = phaseE ? lamE : lamH;
@@ -796,14 +807,11 @@ int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArg
   for (int n = 0; n < 6; ++n) { a.hull[n] = boxes.hull[n]; a.core[n] = boxes.core[n]; }
   a.rot_shift = boxes.rot_shift;
   // (x-slabs exchange planes of `work` between ranks: every cell's entry has to exist)
-  static const bool direct_allowed = [] {
-    const char* e = getenv("FDTDHIP_ADJ_DIRECT");
-    return !e || atoi(e) != 0;
-  }();
   // (pass 1 is then launched box by box with planes and row quads as grid dimensions)
-  a.direct = direct_allowed && a.mat_const && !p->H_below && !p->E_above && p->nx <= 65535 &&
+  const int mode = adjoint_direct_mode();
+  a.direct = mode > 0 && a.mat_const && !p->H_below && !p->E_above && p->nx <= 65535 &&
                      (p->ny + 3) / 4 <= 65535 &&
-                     (adjoint_rows(p) || p->cells() > (int64_t)(1 << 19)) ? 1 : 0;
+                     (mode > 1 || adjoint_rows(p) || p->cells() > (int64_t)(1 << 19)) ? 1 : 0;
   return 0;
 }
 
@@ -948,7 +956,7 @@ bool adjoint_pairs_eligible(const fdtdhip_plan* p) {
     const char* e = getenv("FDTDHIP_FUSED");
     return e ? (atoi(e) ? 1 : 0) : -1;
   }();
-  if (mode == 0) return false;
+  if (mode == 0 || adjoint_direct_mode() > 1) return false;
   if (mode < 0 && p->cells() > (int64_t)(1 << 19)) return false;
   if (adjoint_rows(p)) return false;   // (never true below 2^19 cells by default; keeps the flat mapping)
   for (const BoundaryRef& b : p->boundaries)

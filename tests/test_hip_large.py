@@ -269,21 +269,25 @@ def test_one_launch_step_forced_on_and_off(fused):
     assert " passed" in done.stdout
 
 
-def test_adjoint_without_the_direct_gather():
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_adjoint_with_the_direct_gather_forced_off_and_on(mode):
     """On large grids the second adjoint pass derives the difference adjoints of cells far
-    from PMLs and objects from the field adjoint itself and the first pass leaves those cells
-    out.  FDTDHIP_ADJ_DIRECT=0 keeps the plain two-pass form everywhere (the form x-slabs
-    always use): the finite-difference checks on larger scenes must hold for it too.  Read
-    once per process, hence the child process."""
+    from PMLs and objects from the field adjoint itself, and the first pass runs over boxes
+    that cover the other cells only.  FDTDHIP_ADJ_DIRECT=0 keeps the plain two-pass form
+    everywhere (the form x-slabs always use), =2 applies the direct form to grids of any
+    size: the gradients of the reference's autograd and the finite-difference checks must
+    hold either way.  Read once per process, hence the child process."""
     import os
     import subprocess
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, FDTDHIP_ADJ_DIRECT="0")
+    env = dict(os.environ, FDTDHIP_ADJ_DIRECT=mode)
     done = subprocess.run(
-        [sys.executable, "-m", "pytest", os.path.join(here, "test_fuzz.py"), "-q", "-x", "-m", "gpu",
-         "-k", "larger_scenes_adjoint", "-p", "no:cacheprovider"],
+        [sys.executable, "-m", "pytest", os.path.join(here, "test_fuzz.py"),
+         os.path.join(here, "test_adjoint.py"), "-q", "-x", "-m", "gpu",
+         "-k", "adjoint_against_finite or gradients_match_reference_autograd or finite_differences",
+         "-p", "no:cacheprovider"],
         env=env, capture_output=True, text=True, timeout=280, cwd=os.path.dirname(here))
     assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
     assert " passed" in done.stdout
