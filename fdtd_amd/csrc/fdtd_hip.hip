@@ -806,10 +806,9 @@ int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArg
   fill_core<T>(p, boxes);
   for (int n = 0; n < 6; ++n) { a.hull[n] = boxes.hull[n]; a.core[n] = boxes.core[n]; }
   a.rot_shift = boxes.rot_shift;
-  // (x-slabs exchange planes of `work` between ranks: every cell's entry has to exist)
   // (pass 1 is then launched box by box with planes and row quads as grid dimensions)
   const int mode = adjoint_direct_mode();
-  a.direct = mode > 0 && a.mat_const && !p->H_below && !p->E_above && p->nx <= 65535 &&
+  a.direct = mode > 0 && a.mat_const && p->nx <= 65535 &&
                      (p->ny + 3) / 4 <= 65535 &&
                      (mode > 1 || adjoint_rows(p) || p->cells() > (int64_t)(1 << 19)) ? 1 : 0;
   return 0;
@@ -896,6 +895,8 @@ int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
     for (int d = 0; d < 3; ++d) {
       s0[d] = a.core[2 * d] + (a.core[2 * d] > 0 ? 1 : 0);
       s1[d] = a.core[2 * d + 1] - (a.core[2 * d + 1] < n[d] ? 1 : 0);
+      if (d == 0 && a.open_lo) s0[d] = std::max(s0[d], 1);          // the planes at an open
+      if (d == 0 && a.open_hi) s1[d] = std::min(s1[d], n[d] - 1);   // face always have a pass 1
       s0[d] = std::min(std::max(s0[d], 0), n[d]);
       s1[d] = std::min(std::max(s1[d], s0[d]), n[d]);
     }

@@ -135,10 +135,15 @@ __device__ __forceinline__ bool adj_any_obj(const AdjArgs<T>& a, int i, int j, i
 // leaves a cell out when every cell that could read its entry -- itself and its six
 // neighbours' gathers, all of which reach at most one cell further -- takes the direct
 // form, i.e. when the 3 x 3 x 3 block around it is plain.  Inclusive cell ranges, clamped
-// to the grid.
+// to the grid -- except across the open faces of an x-slab, where nothing is plain: the
+// planes next to such a face keep the two-pass form, and with it the planes of `work` the
+// ranks exchange.
 template <typename T>
 __device__ __forceinline__ bool adj_box_plain(const AdjArgs<T>& a, int i0, int i1, int j0, int j1,
                                               int k0, int k1) {
+  // across an open face of an x-slab lies another rank's plane: its difference adjoints
+  // arrive as a plane of `work`, and this rank's plane at the face is sent as one
+  if ((a.open_lo && i0 < 0) || (a.open_hi && i1 > a.nx - 1)) return false;
   i0 = max(i0, 0); j0 = max(j0, 0); k0 = max(k0, 0);
   i1 = min(i1, a.nx - 1); j1 = min(j1, a.ny - 1); k1 = min(k1, a.nz - 1);
   const bool in_core = i0 >= a.core[0] && i1 < a.core[1] && j0 >= a.core[2] && j1 < a.core[3] &&

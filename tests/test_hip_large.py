@@ -274,7 +274,7 @@ def test_adjoint_with_the_direct_gather_forced_off_and_on(mode):
     """On large grids the second adjoint pass derives the difference adjoints of cells far
     from PMLs and objects from the field adjoint itself, and the first pass runs over boxes
     that cover the other cells only.  FDTDHIP_ADJ_DIRECT=0 keeps the plain two-pass form
-    everywhere (the form x-slabs always use), =2 applies the direct form to grids of any
+    everywhere, =2 applies the direct form to grids of any
     size: the gradients of the reference's autograd and the finite-difference checks must
     hold either way.  Read once per process, hence the child process."""
     import os

@@ -336,3 +336,22 @@ def test_random_scenes_slab_gradients_gpu(tmp_path):
     seeds, bad = fuzz_slab_adjoint.run(3, 100, 90, str(tmp_path / "adj.npz"))
     assert len(seeds) >= 20
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_random_scenes_slab_gradients_direct_gather_gpu(tmp_path, monkeypatch):
+    """The same with the ranks' reverse sweeps in the form large grids take (difference
+    adjoints of cells far from PMLs, objects and the open faces of the slab derived from the
+    field adjoint; FDTDHIP_ADJ_DIRECT=2 applies it at any size), also on slabs of one or two
+    planes, where every plane lies at an open face."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_slab_adjoint
+
+    monkeypatch.setenv("FDTDHIP_ADJ_DIRECT", "2")
+    seeds, bad = fuzz_slab_adjoint.run(3, 300, 60, str(tmp_path / "adj.npz"))
+    assert len(seeds) >= 15
+    assert not bad, bad
+    monkeypatch.setenv("FUZZ_THIN_X", "5")
+    seeds, bad = fuzz_slab_adjoint.run(5, 100, 30, str(tmp_path / "adj_thin.npz"))
+    assert len(seeds) >= 8
+    assert not bad, bad
