@@ -294,7 +294,11 @@ int fdtdhip_adjoint_run(fdtdhip_plan* plan, int64_t nsteps, void* lamE, void* la
  *                            H half step the LAST work plane of the rank below, each a
  *                            contiguous (ny, nz, 6) block exchanged by the caller between
  *                            the two calls; NULL where the slab ends at a domain edge.
- * A reverse step undoes the H half step first (phase_E = 0), then the E half step. */
+ * A reverse step undoes the H half step first (phase_E = 0), then the E half step.
+ * `work` belongs to the two calls of a half step: where the materials are proven constants
+ * the library leaves out the entries of cells far from every PML, object and open slab
+ * face and derives them inside the gather instead, so the caller may rely on the first and
+ * last plane of an open slab only (the planes it exchanges). */
 int fdtdhip_adjoint_cells(fdtdhip_plan* plan, int phase_E, int64_t step, void* lamE, void* lamH,
                           void* work);
 int fdtdhip_adjoint_gather(fdtdhip_plan* plan, int phase_E, void* lamE, void* lamH, void* work,
