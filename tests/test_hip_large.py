@@ -1,7 +1,7 @@
 """The large-grid kernels (the ones bench.py measures) against the oracle and against
 each other, on a real MI355X.
 
-The library picks its kernels by plane size: grids whose (y, z) plane has 4096 cells
+The library picks its kernels by plane size: grids whose (y, z) plane has 1024 cells
 or more run the unconditional-load kernels (row lane mapping with rotated z segments
 when the rows fill their 64-lane segments -- the 128- and 192-cell rows below --, flat
 mapping otherwise; non-temporal access), smaller ones the shape-agnostic kernels the golden scenes exercise.  Here
