@@ -8,6 +8,7 @@ stepwise the same, advanced one step per autograd node (how reference
          cortical/autoencoder.py:108-109 drives the grid)
 large    256^3 float32, 6 PML(10), learnable 64^3 box, 40 steps forward and backward
 xlarge   the same at 512^3, 20 steps
+plane2d  3000x3000x1 float32, 4 PML(10), learnable 64x64 box, 40 steps
 Prints one JSON line per workload: milliseconds per step for forward and for backward.
 """
 import argparse
@@ -31,6 +32,15 @@ def build(kind):
         g[28:68, 40:60, 0:1] = fdtd.LearnableAnisotropicObject(permittivity=2.5)
         return g, 200, (slice(40, 56), 80, slice(0, 1))
     fdtd.set_backend("hip.float32")
+    if kind == "plane2d":
+        g = fdtd.Grid((3000, 3000, 1))
+        g[0:10, :, :] = fdtd.PML()
+        g[-10:, :, :] = fdtd.PML()
+        g[:, 0:10, :] = fdtd.PML()
+        g[:, -10:, :] = fdtd.PML()
+        g[1500, 1400, 0] = fdtd.PointSource(period=20)
+        g[1468:1532, 1468:1532, 0:1] = fdtd.LearnableAnisotropicObject(permittivity=2.5)
+        return g, 40, (slice(1490, 1510), 1540, slice(0, 1))
     if kind == "xlarge":
         g = fdtd.Grid((512, 512, 512))
         for axis in range(3):
