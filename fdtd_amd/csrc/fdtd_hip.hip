@@ -912,9 +912,10 @@ int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
                        std::max(a.hull[4] - 1, s0[2]), std::min(a.hull[5] + 1, s1[2])});
     for (const CellBox& b : boxes) {
       if (b.i1 <= b.i0 || b.j1 <= b.j0 || b.k1 <= b.k0) continue;
-      const bool thin = b.k1 - b.k0 <= 16;   // 16 cells of 4 rows per wave (box_lane_cell)
-      const dim3 grid(thin ? 1 : (b.k1 - b.k0 + 63) / 64, (b.j1 - b.j0 + (thin ? 15 : 3)) / (thin ? 16 : 4),
-                      b.i1 - b.i0);
+      const bool thin = b.k1 - b.k0 <= 16;   // several short rows per wave (box_lane_cell)
+      const int rows_per_block = thin ? 4 * (64 >> thin_box_shift(b.k1 - b.k0)) : 4;
+      const dim3 grid(thin ? 1 : (b.k1 - b.k0 + 63) / 64,
+                      (b.j1 - b.j0 + rows_per_block - 1) / rows_per_block, b.i1 - b.i0);
       if (phaseE) hipLaunchKernelGGL((adj_E_cells<T, true, true>), grid, block, 0, p->stream, a, b);
       else hipLaunchKernelGGL((adj_H_cells<T, true, true>), grid, block, 0, p->stream, a, b);
     }

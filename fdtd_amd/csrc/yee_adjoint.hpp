@@ -43,14 +43,19 @@ __device__ __forceinline__ bool adj_lane_cell(const AdjArgs<T>& a, int& i, int& 
 // piece of a z row of the box, 4 rows per workgroup (thin boxes: see box_lane_cell).
 struct CellBox { int i0, i1, j0, j1, k0, k1; };
 
-// A box at most 16 cells deep along z (a z-face slab) gives each wave 16 cells of 4 rows
-// instead of a quarter-filled 64-cell segment: 16 rows per workgroup.
+// A box at most 16 cells deep along z (a z-face slab, a 2-D grid) gives each wave several
+// rows of 1, 2, 4, 8 or 16 cells instead of a mostly empty 64-cell segment.
+__host__ __device__ __forceinline__ int thin_box_shift(int depth) {
+  return depth <= 1 ? 0 : (depth <= 2 ? 1 : (depth <= 4 ? 2 : (depth <= 8 ? 3 : 4)));
+}
+
 __device__ __forceinline__ bool box_lane_cell(const CellBox& b, int& i, int& j, int& k) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   i = b.i0 + blockIdx.z;
   if (b.k1 - b.k0 <= 16) {
-    k = b.k0 + (lane & 15);
-    j = b.j0 + (blockIdx.y * 4 + wave) * 4 + (lane >> 4);
+    const int sh = thin_box_shift(b.k1 - b.k0);
+    k = b.k0 + (lane & ((1 << sh) - 1));
+    j = b.j0 + (blockIdx.y * 4 + wave) * (64 >> sh) + (lane >> sh);
   } else {
     k = b.k0 + blockIdx.x * 64 + lane;
     j = b.j0 + blockIdx.y * 4 + wave;
