@@ -30,6 +30,10 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+const char* const kPoisoned =
+    "an earlier fused step failed half way: the plan's state is split between its two buffer "
+    "sets; call fdtdhip_plan_reset (and set the fields again) before stepping";
+
 #define HIPCHK(expr)                                                                      \
   do {                                                                                    \
     hipError_t _e = (expr);                                                               \
@@ -37,18 +41,27 @@ int fail(int code, const std::string& msg) {
       return fail(-2, std::string(#expr) + ": " + hipGetErrorString(_e));                 \
   } while (0)
 
+// Makes the plan's device current for the duration of a call.  `ok` is false when that
+// could not be done: nothing may be enqueued then (it would land on another device).
 struct DeviceGuard {
   int prev = -1;
   bool switched = false;
+  bool ok = true;
   explicit DeviceGuard(int dev) {
-    if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+    if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+    if (prev != dev) {
       switched = hipSetDevice(dev) == hipSuccess;
+      ok = switched;
     }
   }
   ~DeviceGuard() {
     if (switched) (void)hipSetDevice(prev);
   }
 };
+
+#define GUARD(p)                 \
+  DeviceGuard g((p)->device);    \
+  if (!g.ok) return fail(-2, "could not make the plan's device current (hipSetDevice)")
 
 struct PmlH {
   int axis, side, t, lo;
@@ -131,6 +144,8 @@ struct fdtdhip_plan {
   const void *H_below = nullptr, *E_above = nullptr;
   void *E_alt = nullptr, *H_alt = nullptr;  // second field pair of the fused full step
   bool step_flipped = false;                // an odd number of fused steps has been taken
+  bool poisoned = false;                    // a fused step failed while the state lived in the
+                                            // second buffers: only reset / destroy are accepted
   std::vector<BoundaryRef> boundaries;
   std::vector<PmlH> pmls;
   std::vector<ObjH> objs;
@@ -180,6 +195,7 @@ int release_tables(fdtdhip_plan* p) {
   p->trace_cursor = -1;
   p->pml_dirty = true;
   p->step_flipped = false;
+  p->poisoned = false;
   p->boundaries.clear();
   p->pmls.clear();
   p->objs.clear();
@@ -456,6 +472,7 @@ int scan_material(fdtdhip_plan* p, int w) {
 
 template <typename T>
 int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
+  if (p->poisoned) return fail(-5, kPoisoned);
   if (!p->E || !p->H || !p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
   if (x0 < 0 || x1 > p->nx || x0 > x1) return fail(-1, "bad x range");
   if (x0 == x1) return 0;
@@ -608,6 +625,7 @@ int read_current(fdtdhip_plan* p, DetH& d) {
   hipLaunchKernelGGL((detect_current<T>), dim3(blocks_for(d.n, 64)), dim3(64), 0, p->stream,
                      (const T*)p->H, (const T*)d.below, d.xyz, out, d.n, p->nx, p->ny, p->nz,
                      (T)d.spacing);
+  HIPCHK(hipGetLastError());
   ++d.usedH;
   return 0;
 }
@@ -615,6 +633,7 @@ int read_current(fdtdhip_plan* p, DetH& d) {
 template <typename T>
 int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 = 0, int x1 = -1,
          int stage = -1) {
+  if (p->poisoned) return fail(-5, kPoisoned);
   T* F = (T*)(phaseE ? p->E : p->H);
   const T* mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
   if (!F || !mat) return fail(-1, "fields not set");
@@ -648,12 +667,14 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
       const int dst = phaseE ? 0 : n - 1, src = phaseE ? n - 1 : 0;
       hipLaunchKernelGGL((periodic_copy<T>), dim3(blocks_for(total)), dim3(256), 0, p->stream, F,
                          p->nx, p->ny, p->nz, axis, dst, src);
+      HIPCHK(hipGetLastError());
     } else if (seen_periodic && active) {
       const PmlH& h = p->pmls[b.idx];
       PmlK<T> k = make_pmlk<T>(p, h, phaseE);
       const int64_t slab = (int64_t)(h.axis == 0 ? h.t : p->nx) * k.sy * k.sz;
       hipLaunchKernelGGL((pml_apply_slab<T>), dim3(blocks_for(slab)), dim3(256), 0, p->stream, F,
                          mat, k, p->nx, p->ny, p->nz, (T)p->sc, phaseE ? T(1) : T(-1));
+      HIPCHK(hipGetLastError());
     }
   }
   for (SourceH& s : p->sources) {
@@ -670,6 +691,7 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
       hipLaunchKernelGGL((source_soft_point<T>), dim3(1), dim3(1), 0, p->stream, F, s.elem0, s.wave,
                          s.nwave, q, s.impedance, s.spacing, cur,
                          s.vin ? (T*)s.vin + s.vused : nullptr, s.vout ? (T*)s.vout + s.vused : nullptr);
+      HIPCHK(hipGetLastError());
       if (s.vin) ++s.vused;
       continue;
     }
@@ -685,6 +707,7 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
                          (T*)p->E, (const T*)p->H, p->ny, p->nz, s.box[0], s.box[1], s.box[2],
                          s.box[3], s.box[4], s.box[5], s.compE, (const T*)s.modP,
                          (const T*)s.osc + row * s.channels, (const T*)s.modw, s.channels, et);
+      HIPCHK(hipGetLastError());
       continue;
     }
     const double w = waveform(s, q);
@@ -694,6 +717,7 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
       hipLaunchKernelGGL((source_add_points<T>), dim3(s.serial ? 1 : blocks_for(s.n, 64)),
                          dim3(64), 0, p->stream, F, s.elem, s.profile, w, s.n, s.serial, elem_lo,
                          elem_hi);
+      HIPCHK(hipGetLastError());
     } else {
       const int64_t total =
           (int64_t)(s.box[1] - s.box[0]) * (s.box[3] - s.box[2]) * (s.box[5] - s.box[4]);
@@ -701,6 +725,7 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
       hipLaunchKernelGGL((source_set_box<T>), dim3(blocks_for(total)), dim3(256), 0, p->stream, F,
                          p->ny, p->nz, s.box[0], s.box[1], s.box[2], s.box[3], s.box[4], s.box[5],
                          phaseE ? s.compE : s.compH, (T)(s.amplitude * w));
+      HIPCHK(hipGetLastError());
     }
   }
   // cell-list detectors share launches (up to MAX_DET_BATCH per launch); reading a field
@@ -708,11 +733,13 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
   DetBatch<T> batch;
   batch.count = 0;
   batch.first[0] = 0;
-  auto flush = [&]() {
-    if (batch.count == 0) return;
+  auto flush = [&]() -> int {
+    if (batch.count == 0) return 0;
     hipLaunchKernelGGL((detect_cells_batch<T>), dim3(blocks_for(batch.first[batch.count])),
                        dim3(256), 0, p->stream, F, batch);
     batch.count = 0;
+    HIPCHK(hipGetLastError());
+    return 0;
   };
   for (DetH& d : p->dets) {
     if (!(parts & POST_FINISH)) break;
@@ -721,19 +748,21 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
       int64_t& used = phaseE ? d.usedE : d.usedH;
       char* base = phaseE ? d.outE : d.outH;
       if (d.n == 0) { ++used; continue; }
-      if (!base || used >= d.capacity) { flush(); return fail(-3, "detector output capacity exhausted"); }
+      if (!base || used >= d.capacity) {
+        if (int rc = flush()) return rc;
+        return fail(-3, "detector output capacity exhausted");
+      }
       batch.cell[batch.count] = d.cell;
       batch.out[batch.count] = (T*)base + used * d.n * 3;
       batch.first[batch.count + 1] = batch.first[batch.count] + d.n * 3;
-      if (++batch.count == MAX_DET_BATCH) flush();
       ++used;
+      if (++batch.count == MAX_DET_BATCH)
+        if (int rc = flush()) return rc;
     } else if (!phaseE && !d.below) {
-      if (int rc = read_current<T>(p, d)) { flush(); return rc; }
+      if (int rc = read_current<T>(p, d)) { (void)flush(); return rc; }
     }
   }
-  flush();
-  HIPCHK(hipGetLastError());
-  return 0;
+  return flush();
 }
 
 // The current detectors that wait for the plane under the slab (fdtdhip_plan_set_detector_below).
@@ -1052,6 +1081,7 @@ bool fused_eligible(const fdtdhip_plan* p) {
     return false;
   if (p->H_below || p->E_above) return false;
   if (p->nx > 65535 || (int64_t)p->ny * p->nz >= (1ll << 30)) return false;
+  if (p->cells() * 3 >= (1ll << 31)) return false;   // the kernel's element offsets are 32-bit
   for (const BoundaryRef& b : p->boundaries)
     if (b.kind == 1) return false;
   for (const PmlH& h : p->pmls)
@@ -1064,9 +1094,25 @@ bool fused_eligible(const fdtdhip_plan* p) {
   return points <= MAX_STEP_SOURCES;
 }
 
+// Room for `n` more readings of every detector, checked before a fused pair of steps
+// enqueues anything (a failure between its two steps would strand the state in the second
+// buffers).
+int capacity_check(const fdtdhip_plan* p, int64_t n) {
+  for (const DetH& d : p->dets) {
+    if (d.n == 0) continue;
+    const bool cells = d.kind == FDTDHIP_DET_CELLS;
+    if (!cells && d.below) continue;   // read on request (fdtdhip_read_deferred_currents)
+    if (!d.outH || (cells && !d.outE) || d.usedH + n > d.capacity ||
+        (cells && d.usedE + n > d.capacity))
+      return fail(-3, "detector output capacity exhausted");
+  }
+  return 0;
+}
+
 // Build the detector map of the fused step once per plan layout.
 int build_detmap(fdtdhip_plan* p) {
   p->detmap_state = -1;
+  p->detmap = nullptr;   // an earlier map stays in `owned` until the plan is reset
   int cells_dets = 0;
   for (const DetH& d : p->dets)
     if (d.kind == FDTDHIP_DET_CELLS && d.n > 0) ++cells_dets;
@@ -1103,6 +1149,7 @@ int fused_step(fdtdhip_plan* p, int64_t q) {
       if (d.kind != FDTDHIP_DET_CELLS || d.n == 0) continue;
       if (!d.outE || !d.outH || d.usedE >= d.capacity || d.usedH >= d.capacity)
         return fail(-3, "detector output capacity exhausted");
+      if (slot >= MAX_STEP_DETECTORS) return fail(-1, "detector map out of date");
       a.detE[slot] = (T*)d.outE + d.usedE * d.n * 3;
       a.detH[slot] = (T*)d.outH + d.usedH * d.n * 3;
       ++slot;
@@ -1216,7 +1263,7 @@ int fdtdhip_plan_create(fdtdhip_plan** out, int nx, int ny, int nz, int dtype, d
 
 int fdtdhip_plan_reset(fdtdhip_plan* p) {
   if (!p) return fail(-1, "null plan");
-  DeviceGuard g(p->device);
+  GUARD(p);
   (void)hipStreamSynchronize(p->stream);
   return release_tables(p);
 }
@@ -1224,7 +1271,7 @@ int fdtdhip_plan_reset(fdtdhip_plan* p) {
 int fdtdhip_plan_destroy(fdtdhip_plan* p) {
   if (!p) return 0;
   {
-    DeviceGuard g(p->device);
+    DeviceGuard g(p->device);   // best effort: the host side is released in any case
     (void)hipStreamSynchronize(p->stream);
     release_tables(p);
     if (p->pml_tables) (void)hipFree(p->pml_tables);
@@ -1263,7 +1310,7 @@ int fdtdhip_plan_scan_materials(fdtdhip_plan* p, int enable) {
   }();
   p->mat_const[0] = p->mat_const[1] = false;
   if (off || !enable) return 0;
-  DeviceGuard g(p->device);
+  GUARD(p);
   for (int w = 0; w < 2; ++w)
     if (int rc = DISPATCH(p, scan_material<float>(p, w), scan_material<double>(p, w))) return rc;
   return (p->mat_const[0] ? 1 : 0) | (p->mat_const[1] ? 2 : 0);
@@ -1300,7 +1347,7 @@ int fdtdhip_plan_add_pml(fdtdhip_plan* p, int axis, int side, int t, const doubl
   if (t < 1 || t > n) return fail(-1, "PML thickness out of range");
   if (!bE || !cE || !bH || !cH || !psiE || !psiH) return fail(-1, "null PML array");
   if ((int)p->pmls.size() >= fdtdhip::MAX_PML) return fail(-1, "too many PMLs (one per face)");
-  DeviceGuard g(p->device);
+  GUARD(p);
   PmlH h;
   h.axis = axis; h.side = side; h.t = t; h.lo = side == 0 ? 0 : n - t;
   h.psiE = psiE; h.psiH = psiH;
@@ -1367,7 +1414,7 @@ int fdtdhip_plan_add_source(fdtdhip_plan* p, int kind, int compE, int compH, int
   if (!p) return fail(-1, "null plan");
   if (!cells || !profile) return fail(-1, "null source array");
   if (compE < 0 || compE > 2 || compH < 0 || compH > 2) return fail(-1, "bad component");
-  DeviceGuard g(p->device);
+  GUARD(p);
   SourceH s;
   s.kind = kind; s.compE = compE; s.compH = compH; s.n = n;
   s.period = period; s.phase = phase; s.pulse = pulse; s.frequency = frequency;
@@ -1417,7 +1464,7 @@ int fdtdhip_plan_add_soft_source(fdtdhip_plan* p, const int32_t cell[3], const d
   const int lim[3] = {p->nx, p->ny, p->nz};
   for (int a = 0; a < 3; ++a)
     if (cell[a] < 0 || cell[a] >= lim[a]) return fail(-1, "source cell outside the grid");
-  DeviceGuard g(p->device);
+  GUARD(p);
   SourceH s;
   s.kind = FDTDHIP_SRC_SOFT_POINT;
   s.compE = s.compH = 2; s.n = 1;
@@ -1495,7 +1542,7 @@ int fdtdhip_plan_add_detector(fdtdhip_plan* p, int kind, int64_t n, const int32_
                               double spacing) {
   if (!p) return fail(-1, "null plan");
   if (n < 0 || (n > 0 && !cells)) return fail(-1, "bad detector point list");
-  DeviceGuard g(p->device);
+  GUARD(p);
   DetH d;
   d.kind = kind; d.n = n; d.spacing = spacing;
   const int lim[3] = {p->nx, p->ny, p->nz};
@@ -1523,6 +1570,7 @@ int fdtdhip_plan_add_detector(fdtdhip_plan* p, int kind, int64_t n, const int32_
     return fail(-1, "unknown detector kind");
   }
   p->dets.push_back(d);
+  p->detmap_state = 0;   // the fused step's cell -> detector map no longer covers every detector
   return (int)p->dets.size() - 1;
 }
 
@@ -1547,41 +1595,41 @@ int fdtdhip_plan_set_detector_below(fdtdhip_plan* p, int id, const void* H_plane
 
 int fdtdhip_read_deferred_currents(fdtdhip_plan* p) {
   if (!p) return fail(-1, "null plan");
-  DeviceGuard g(p->device);
+  GUARD(p);
   return DISPATCH(p, read_deferred_currents<float>(p), read_deferred_currents<double>(p));
 }
 
 int fdtdhip_update_E_bulk(fdtdhip_plan* p, int x0, int x1) {
   if (!p) return fail(-1, "null plan");
-  DeviceGuard g(p->device);
+  GUARD(p);
   return DISPATCH(p, bulk<float>(p, true, x0, x1), bulk<double>(p, true, x0, x1));
 }
 int fdtdhip_update_H_bulk(fdtdhip_plan* p, int x0, int x1) {
   if (!p) return fail(-1, "null plan");
-  DeviceGuard g(p->device);
+  GUARD(p);
   return DISPATCH(p, bulk<float>(p, false, x0, x1), bulk<double>(p, false, x0, x1));
 }
 int fdtdhip_update_E_post(fdtdhip_plan* p, int64_t q) {
   if (!p) return fail(-1, "null plan");
-  DeviceGuard g(p->device);
+  GUARD(p);
   return DISPATCH(p, post<float>(p, true, q), post<double>(p, true, q));
 }
 int fdtdhip_update_H_post(fdtdhip_plan* p, int64_t q) {
   if (!p) return fail(-1, "null plan");
-  DeviceGuard g(p->device);
+  GUARD(p);
   return DISPATCH(p, post<float>(p, false, q), post<double>(p, false, q));
 }
 int fdtdhip_update_E_post_stage(fdtdhip_plan* p, int64_t q, int stage) {
   if (!p) return fail(-1, "null plan");
   if (stage != 0 && stage != 1) return fail(-1, "stage is 0 or 1");
-  DeviceGuard g(p->device);
+  GUARD(p);
   return DISPATCH(p, post<float>(p, true, q, POST_ALL, 0, -1, stage),
                   post<double>(p, true, q, POST_ALL, 0, -1, stage));
 }
 int fdtdhip_update_H_post_stage(fdtdhip_plan* p, int64_t q, int stage) {
   if (!p) return fail(-1, "null plan");
   if (stage != 0 && stage != 1) return fail(-1, "stage is 0 or 1");
-  DeviceGuard g(p->device);
+  GUARD(p);
   return DISPATCH(p, post<float>(p, false, q, POST_ALL, 0, -1, stage),
                   post<double>(p, false, q, POST_ALL, 0, -1, stage));
 }
@@ -1603,12 +1651,19 @@ int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
   if (fused_eligible(p)) {
     // pairs of fused steps: first -> second buffers and back, so that the state ends
     // where the caller's tensors are; an odd last step runs as two half steps
-    DeviceGuard g(p->device);
-    for (; s + 1 < nsteps; s += 2)
+    GUARD(p);
+    if (p->poisoned) return fail(-5, kPoisoned);
+    for (; s + 1 < nsteps; s += 2) {
+      if (int rc = capacity_check(p, 2)) return rc;
       for (int k = 0; k < 2; ++k) {
         const int rc = DISPATCH(p, fused_step<float>(p, q0 + s + k), fused_step<double>(p, q0 + s + k));
-        if (rc) return rc;
+        if (rc) {
+          // the state of the fields now sits in the second buffers (or between the two sets)
+          if (p->step_flipped) p->poisoned = true;
+          return rc;
+        }
       }
+    }
   }
   for (; s < nsteps; ++s) {
     if (int rc = fdtdhip_update_E(p, q0 + s)) return rc;
@@ -1666,7 +1721,7 @@ int fdtdhip_plan_set_pml_adjoint(fdtdhip_plan* p, int id, void* lam_psiE, void* 
 int fdtdhip_adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH, void* work) {
   if (!p) return fail(-1, "null plan");
   if (!lamE || !lamH || !work) return fail(-1, "null adjoint array");
-  DeviceGuard g(p->device);
+  GUARD(p);
   return DISPATCH(p, adjoint_run<float>(p, nsteps, lamE, lamH, work),
                   adjoint_run<double>(p, nsteps, lamE, lamH, work));
 }
@@ -1674,7 +1729,7 @@ int fdtdhip_adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH,
 int fdtdhip_adjoint_cells(fdtdhip_plan* p, int phase_E, int64_t step, void* lamE, void* lamH,
                           void* work) {
   if (!p) return fail(-1, "null plan");
-  DeviceGuard g(p->device);
+  GUARD(p);
   p->trace_cursor = step;
   const int rc = DISPATCH(p, adjoint_cells<float>(p, phase_E != 0, (float*)lamE, (float*)lamH, (float*)work),
                           adjoint_cells<double>(p, phase_E != 0, (double*)lamE, (double*)lamH, (double*)work));
@@ -1685,7 +1740,7 @@ int fdtdhip_adjoint_cells(fdtdhip_plan* p, int phase_E, int64_t step, void* lamE
 int fdtdhip_adjoint_gather(fdtdhip_plan* p, int phase_E, void* lamE, void* lamH, void* work,
                            const void* work_ghost) {
   if (!p) return fail(-1, "null plan");
-  DeviceGuard g(p->device);
+  GUARD(p);
   return DISPATCH(p, adjoint_gather<float>(p, phase_E != 0, (float*)lamE, (float*)lamH, (float*)work,
                                            (const float*)work_ghost),
                   adjoint_gather<double>(p, phase_E != 0, (double*)lamE, (double*)lamH, (double*)work,
@@ -1698,7 +1753,7 @@ int fdtdhip_plane_energy(fdtdhip_plan* p, int axis, int index, void* outE, void*
   if (!outE || !outH) return fail(-1, "null output");
   const int n = axis == 0 ? p->nx : (axis == 1 ? p->ny : p->nz);
   if (axis < 0 || axis > 2 || index < 0 || index >= n) return fail(-1, "plane outside the grid");
-  DeviceGuard g(p->device);
+  GUARD(p);
   const int64_t cells = p->cells() / n;
   if (p->dtype == FDTDHIP_F32)
     hipLaunchKernelGGL((plane_energy<float>), dim3(blocks_for(cells)), dim3(256), 0, p->stream,
@@ -1714,7 +1769,7 @@ int fdtdhip_plane_energy(fdtdhip_plan* p, int axis, int index, void* outE, void*
 
 int fdtdhip_plan_enable_timing(fdtdhip_plan* p, int on) {
   if (!p) return fail(-1, "null plan");
-  DeviceGuard g(p->device);
+  GUARD(p);
   if (int rc = drain_timing(p)) return rc;
   p->timing = on != 0;
   p->ms[0] = p->ms[1] = 0;
@@ -1725,7 +1780,7 @@ int fdtdhip_plan_enable_timing(fdtdhip_plan* p, int on) {
 int fdtdhip_plan_get_timing(fdtdhip_plan* p, double* ms_E, int64_t* launches_E, double* ms_H,
                             int64_t* launches_H) {
   if (!p) return fail(-1, "null plan");
-  DeviceGuard g(p->device);
+  GUARD(p);
   if (int rc = drain_timing(p)) return rc;
   if (ms_E) *ms_E = p->ms[1];
   if (launches_E) *launches_E = p->launches[1];
