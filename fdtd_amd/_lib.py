@@ -61,6 +61,7 @@ PROTOTYPES = {
     "fdtdhip_plan_set_object_modifier": (_i, [_p, _i, _p, _p, _p]),
     "fdtdhip_plan_set_pml_adjoint": (_i, [_p, _i, _p, _p]),
     "fdtdhip_adjoint_run": (_i, [_p, _i64, _p, _p, _p]),
+    "fdtdhip_adjoint_run_noalloc": (_i, [_p, _i64, _p, _p]),
     "fdtdhip_adjoint_cells": (_i, [_p, _i, _i64, _p, _p, _p]),
     "fdtdhip_adjoint_gather": (_i, [_p, _i, _p, _p, _p, _p]),
     "fdtdhip_plane_energy": (_i, [_p, _i, _i, _p, _p]),

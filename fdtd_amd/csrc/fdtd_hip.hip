@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -144,6 +145,9 @@ struct fdtdhip_plan {
   const void *H_below = nullptr, *E_above = nullptr;
   void *E_alt = nullptr, *H_alt = nullptr;  // second field pair of the fused full step
   bool step_flipped = false;                // an odd number of fused steps has been taken
+  bool no_alloc = false;                    // inside fdtdhip_adjoint_run_noalloc: device tables
+                                            // live in the static scratch array, nothing may
+                                            // be allocated or freed
   bool poisoned = false;                    // a fused step failed while the state lived in the
                                             // second buffers: only reset / destroy are accepted
   std::vector<BoundaryRef> boundaries;
@@ -241,7 +245,9 @@ int sync_obj_table(fdtdhip_plan* p) {
     tab[o].z0 = h.box[4]; tab[o].z1 = h.box[5];
   }
   const size_t bytes = sizeof(ObjK<T>) * tab.size();
-  if (p->obj_table && p->obj_table_bytes != bytes) {
+  if (p->no_alloc && !tab.empty() && (!p->obj_table || p->obj_table_bytes != bytes))
+    return fail(-6, "internal: object table would have to be allocated");
+  if (!p->no_alloc && p->obj_table && p->obj_table_bytes != bytes) {
     // the old table may still be read by kernels in flight on the plan's stream
     HIPCHK(hipStreamSynchronize(p->stream));
     HIPCHK(hipFree(p->obj_table));
@@ -272,7 +278,10 @@ template <typename T>
 int sync_pml_tables(fdtdhip_plan* p) {
   if (!p->pml_dirty) return 0;
   const size_t bytes = sizeof(PmlK<T>) * MAX_PML * TAB_COUNT;
-  if (!p->pml_tables) HIPCHK(hipMalloc(&p->pml_tables, bytes));
+  if (!p->pml_tables) {
+    if (p->no_alloc) return fail(-6, "internal: PML tables would have to be allocated");
+    HIPCHK(hipMalloc(&p->pml_tables, bytes));
+  }
   std::vector<PmlK<T>> host(MAX_PML * TAB_COUNT);
   for (size_t i = 0; i < p->pmls.size(); ++i) {
     const PmlH& h = p->pmls[i];
@@ -1012,6 +1021,7 @@ int adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH, void* w
     // launch (adj_gather_then_cells), alternating between two work arrays
     const int64_t bytes = p->cells() * 6 * (int64_t)sizeof(T);
     if (p->adj_work_bytes < bytes) {
+      if (p->no_alloc) return fail(-6, "internal: second work array would have to be allocated");
       void* w2 = nullptr;
       HIPCHK(hipMalloc(&w2, (size_t)bytes));
       p->owned.push_back(w2);
@@ -1228,6 +1238,92 @@ int fused_step(fdtdhip_plan* p, int64_t q) {
   }
   if (int rc = post<T>(p, true, q, POST_FINISH)) return rc;
   return post<T>(p, false, q, POST_FINISH);
+}
+
+// ---- reverse sweep without allocations (fdtdhip_adjoint_run_noalloc) -----------------
+// Everything fdtdhip_adjoint_run keeps in device memory besides the caller's arrays -- the
+// `work` array of difference adjoints, the second one of the paired launches, the PML and
+// object descriptor tables -- laid out in one static device array per GPU:
+//   [0, 4 KiB)            PML descriptor tables
+//   [4 KiB, 16 KiB)       object descriptor table (NOALLOC_MAX_OBJECTS entries)
+//   [16 KiB, ...)         work, then the second work array, cells * 6 elements each
+constexpr size_t NOALLOC_PML_OFF = 0, NOALLOC_OBJ_OFF = 4096, NOALLOC_WORK_OFF = 16384;
+constexpr size_t NOALLOC_MAX_OBJECTS = 128;
+static_assert(sizeof(PmlK<double>) * MAX_PML * TAB_COUNT <= NOALLOC_OBJ_OFF - NOALLOC_PML_OFF, "PML tables");
+static_assert(sizeof(ObjK<double>) * NOALLOC_MAX_OBJECTS <= NOALLOC_WORK_OFF - NOALLOC_OBJ_OFF, "object table");
+static_assert(NOALLOC_WORK_OFF % 256 == 0, "work arrays start on a 256-byte boundary");
+
+}  // namespace
+
+// In host code this name is only a handle for hipGetSymbolAddress: every GPU holds its own
+// copy of the array at its own address (noalloc_scratch below).
+static __device__ __align__(256) unsigned char scratch[FDTDHIP_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+
+constexpr int NOALLOC_MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+
+// Device address of `scratch` on `device`, which must be the current device.  Looked up once
+// per device.
+int noalloc_scratch(int device, unsigned char** out) {
+  if (device < 0 || device >= NOALLOC_MAX_DEVICES) return fail(-1, "device ordinal out of range");
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void* ptr = nullptr;
+    HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(-2, "hipGetSymbolAddress returned no address for the scratch array");
+    g_scratch_ptr[device] = (unsigned char*)ptr;
+  }
+  *out = g_scratch_ptr[device];
+  return 0;
+}
+
+template <typename T>
+int adjoint_run_noalloc(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH) {
+  const size_t work_bytes = (size_t)p->cells() * 6 * sizeof(T);
+  const size_t work_stride = (work_bytes + 255) / 256 * 256;   // the second array starts aligned
+  if (p->cells() > (int64_t)(FDTDHIP_NOALLOC_SCRATCH_BYTES / (12 * sizeof(T))) ||
+      NOALLOC_WORK_OFF + work_stride + work_bytes > FDTDHIP_NOALLOC_SCRATCH_BYTES)
+    return fail(-7, "fdtdhip_adjoint_run_noalloc: grid of " + std::to_string(p->cells()) +
+                        " cells needs " + std::to_string(NOALLOC_WORK_OFF + work_stride + work_bytes) +
+                        " bytes of scratch, the static array holds " +
+                        std::to_string((size_t)FDTDHIP_NOALLOC_SCRATCH_BYTES) +
+                        "; use fdtdhip_adjoint_run with a work array of your own");
+  if (p->objs.size() > NOALLOC_MAX_OBJECTS)
+    return fail(-7, "fdtdhip_adjoint_run_noalloc: more than " + std::to_string(NOALLOC_MAX_OBJECTS) +
+                        " objects; use fdtdhip_adjoint_run");
+  unsigned char* base = nullptr;
+  if (int rc = noalloc_scratch(p->device, &base)) return rc;
+  // the scratch array keeps whatever the last call left: both work arrays start at zero,
+  // as the arrays callers hand to fdtdhip_adjoint_run do
+  unsigned char* work = base + NOALLOC_WORK_OFF;
+  HIPCHK(hipMemsetAsync(work, 0, work_stride + work_bytes, p->stream));
+  // point the plan's tables at the scratch array for the duration of the sweep
+  void* const obj_table = p->obj_table;
+  const size_t obj_table_bytes = p->obj_table_bytes;
+  const bool obj_dirty = p->obj_dirty, pml_dirty = p->pml_dirty;
+  void* const pml_tables = p->pml_tables;
+  void* const adj_work = p->adj_work;
+  const int64_t adj_work_bytes = p->adj_work_bytes;
+  p->obj_table = base + NOALLOC_OBJ_OFF;
+  p->obj_table_bytes = sizeof(ObjK<T>) * p->objs.size();
+  p->pml_tables = base + NOALLOC_PML_OFF;
+  p->obj_dirty = p->pml_dirty = true;   // (re)written there by the first kernel set-up
+  p->adj_work = work + work_stride;
+  p->adj_work_bytes = (int64_t)work_bytes;
+  p->no_alloc = true;
+  const int rc = adjoint_run<T>(p, nsteps, lamE, lamH, work);
+  p->no_alloc = false;
+  p->obj_table = obj_table;
+  p->obj_table_bytes = obj_table_bytes;
+  p->pml_tables = pml_tables;
+  p->obj_dirty = obj_dirty;             // the plan's own tables are as current as they were
+  p->pml_dirty = pml_dirty;
+  p->adj_work = adj_work;
+  p->adj_work_bytes = adj_work_bytes;
+  return rc;
 }
 
 #define DISPATCH(p, call_f32, call_f64) ((p)->dtype == FDTDHIP_F32 ? (call_f32) : (call_f64))
@@ -1724,6 +1820,14 @@ int fdtdhip_adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH,
   GUARD(p);
   return DISPATCH(p, adjoint_run<float>(p, nsteps, lamE, lamH, work),
                   adjoint_run<double>(p, nsteps, lamE, lamH, work));
+}
+
+int fdtdhip_adjoint_run_noalloc(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH) {
+  if (!p) return fail(-1, "null plan");
+  if (!lamE || !lamH) return fail(-1, "null adjoint array");
+  GUARD(p);
+  return DISPATCH(p, adjoint_run_noalloc<float>(p, nsteps, lamE, lamH),
+                  adjoint_run_noalloc<double>(p, nsteps, lamE, lamH));
 }
 
 int fdtdhip_adjoint_cells(fdtdhip_plan* p, int phase_E, int64_t step, void* lamE, void* lamH,
