@@ -34,6 +34,16 @@ conversions of the user-facing API are host logic of the engine under test.
 Two extensions that the reference does not have are clearly marked: ghost
 planes for x-slab decomposition (``halo_lo_H`` / ``halo_hi_E``), used only to
 check that a slab-decomposed run equals the single-grid run.
+
+float32 twin.  The reference has no float32 trajectory (its ``*.float32`` backends still
+allocate float64 arrays, reference fdtd/backend.py:87, 265-268), so there is nothing to pin
+one against.  ``OracleGrid(..., dtype=np.float32)`` runs the same slice algebra on float32
+arrays -- every array operation rounds to float32; set-up quantities (PML profiles, source
+amplitudes) are computed in float64 and rounded once, which is what the engine under test
+does -- to tell apart, for a float32 result that is far from the float64 one, inherent
+float32 rounding (twin and engine agree) from a difference in the arithmetic (they do
+not).  With the default ``dtype=np.float64`` nothing changes: that path stays bitwise
+equal to the reference.
 """
 
 from math import pi, sin, cos
@@ -55,7 +65,7 @@ def curl_E(E, halo_hi=None):
     ``halo_hi`` (extension): the E plane that follows the last x plane in a
     slab-decomposed run; with it the x differences of the last plane are kept.
     """
-    out = np.zeros(E.shape)
+    out = np.zeros(E.shape, E.dtype)
     out[:, :-1, :, 0] += E[:, 1:, :, 2] - E[:, :-1, :, 2]
     out[:, :, :-1, 0] -= E[:, :, 1:, 1] - E[:, :, :-1, 1]
     out[:, :, :-1, 1] += E[:, :, 1:, 0] - E[:, :, :-1, 0]
@@ -78,7 +88,7 @@ def curl_H(H, halo_lo=None):
     ``halo_lo`` (extension): the H plane that precedes x plane 0 in a
     slab-decomposed run.
     """
-    out = np.zeros(H.shape)
+    out = np.zeros(H.shape, H.dtype)
     out[:, 1:, :, 0] += H[:, 1:, :, 2] - H[:, :-1, :, 2]
     out[:, :, 1:, 0] -= H[:, :, 1:, 1] - H[:, :, :-1, 1]
     out[:, :, 1:, 1] += H[:, :, 1:, 0] - H[:, :, :-1, 0]
@@ -133,7 +143,8 @@ class OraclePML:
         head[axis] = slice(None, -1)
         self.sigmaH[tuple(head) + (axis,)] = sH.reshape(bshape)
 
-        z = lambda: np.zeros(self.shape + (3,))
+        dt = grid.dtype
+        z = lambda: np.zeros(self.shape + (3,), dt)
         self.phi_E, self.phi_H = z(), z()
         self.psi_E = [z(), z(), z()]  # psi_Ex, psi_Ey, psi_Ez
         self.psi_H = [z(), z(), z()]
@@ -143,6 +154,8 @@ class OraclePML:
         self.cE = (self.bE - 1.0) * self.sigmaE / (self.sigmaE * self.k + self.a * self.k ** 2)
         self.bH = np.exp(-(self.sigmaH / self.k + self.a) * sc)
         self.cH = (self.bH - 1.0) * self.sigmaH / (self.sigmaH * self.k + self.a * self.k ** 2)
+        if dt != np.float64:   # float32 twin: profiles in float64, rounded once
+            self.bE, self.cE, self.bH, self.cH = (v.astype(dt) for v in (self.bE, self.cE, self.bH, self.cH))
 
     # (psi index u, difference axis d, field component w), in the reference's order
     _TERMS = ((0, 1, 2), (0, 2, 1), (1, 2, 0), (1, 0, 2), (2, 0, 1), (2, 1, 0))
@@ -225,10 +238,11 @@ class OracleObject:
         self.grid, self.kind = grid, kind
         self.loc = (slice(x0, x1), slice(y0, y1), slice(z0, z1))
         self.Nx, self.Ny, self.Nz = abs(x1 - x0), abs(y1 - y0), abs(z1 - z0)
+        dt = grid.dtype
         perm = np.array(permittivity)
         if perm.ndim == 3:
             perm = perm[:, :, :, None]
-        inv = np.ones((self.Nx, self.Ny, self.Nz, 3)) / perm
+        inv = np.ones((self.Nx, self.Ny, self.Nz, 3), dt) / perm.astype(dt)
         gi = grid.inverse_permittivity
         x, y, z = self.loc
         if self.Nx > 1:
@@ -240,7 +254,7 @@ class OracleObject:
         gi[x, y, z] = 0
         self.inverse_permittivity = inv
         if kind == "absorbing":
-            cond = np.asarray(conductivity)
+            cond = np.asarray(conductivity).astype(dt)
             while cond.ndim < inv.ndim:
                 cond = cond[..., None]
             cond = np.broadcast_to(cond, inv.shape)
@@ -252,7 +266,7 @@ class OracleObject:
                 if self.Nz != 1:
                     raise ValueError("a substrate object has to be one cell thick along z")
                 self.modifier_weights = np.zeros((9, 3))
-            eye = np.zeros((self.Nx * self.Ny * self.Nz, 3, 3))
+            eye = np.zeros((self.Nx * self.Ny * self.Nz, 3, 3), dt)
             eye[:, range(3), range(3)] = 1.0
             self.inverse_permittivity = np.reshape(
                 np.reshape(inv, (-1, 1, 3)) * eye, (self.Nx, self.Ny, self.Nz, 3, 3)
@@ -339,13 +353,14 @@ class OracleCCPointSource:
         q = self.grid.time_steps_passed
         src = self.amplitude * sin(2 * pi * q / self.period + self.phase_shift)
         x, y, z = self.cell
-        E, d = self.grid.E, self.dir_vec
-        E[x - 1, y, z, 2] -= src * d[0]
-        E[x, y, z, 2] += src * d[0]
-        E[x, y - 1, z, 2] -= src * d[1]
-        E[x, y, z, 2] += src * d[1]
-        E[x, y, z - 1, 2] -= src * d[2]
-        E[x, y, z, 2] += src * d[2]
+        E = self.grid.E
+        d = [self.grid.dtype.type(src * v) for v in self.dir_vec]   # (a no-op in float64)
+        E[x - 1, y, z, 2] -= d[0]
+        E[x, y, z, 2] += d[0]
+        E[x, y - 1, z, 2] -= d[1]
+        E[x, y, z, 2] += d[1]
+        E[x, y, z - 1, 2] -= d[2]
+        E[x, y, z, 2] += d[2]
 
     def update_H(self):
         pass
@@ -367,7 +382,7 @@ class OracleSoftSource:
     def update_E(self):
         q = self.grid.time_steps_passed
         input_voltage = self.waveform_array[q] if q < self.waveform_array.shape[0] else 0.0
-        current = self.current_detector.I[-1][0][0][0] if q > 0 else 0.0
+        current = float(self.current_detector.I[-1][0][0][0]) if q > 0 else 0.0
         if self.impedance > 0:
             output_voltage = input_voltage + self.impedance * current
         else:
@@ -401,7 +416,7 @@ class OracleLineSource:
     def update_E(self):  # reference fdtd/sources.py:316-337
         vect = self.profile * self.wave.factor(self.grid.time_steps_passed)
         for x, y, z, value in zip(self.x, self.y, self.z, vect):
-            self.grid.E[x, y, z, 2] += value
+            self.grid.E[x, y, z, 2] += self.grid.dtype.type(value)
 
     def update_H(self):
         pass
@@ -458,7 +473,7 @@ class OracleBlockDetector:
         self.E, self.H = [], []
 
     def _read(self, F):
-        out = np.empty((len(self.x), len(self.y), len(self.z), 3))
+        out = np.empty((len(self.x), len(self.y), len(self.z), 3), F.dtype)
         for i, row in enumerate(self.x):
             for j, col in enumerate(self.y):
                 for k, pillar in enumerate(self.z):
@@ -494,7 +509,7 @@ class OracleCurrentDetector:
         pass
 
     def detect_H(self):
-        out = np.empty((len(self.x), len(self.y), len(self.z)))
+        out = np.empty((len(self.x), len(self.y), len(self.z)), self.grid.H.dtype)
         for i, row in enumerate(self.x):
             for j, col in enumerate(self.y):
                 for k, pillar in enumerate(self.z):
@@ -509,7 +524,8 @@ class OracleGrid:
     """State + half-step drivers (reference fdtd/grid.py:110-154, 250-325)."""
 
     def __init__(self, shape, grid_spacing=155e-9, permittivity=1.0, permeability=1.0,
-                 courant_number=None):
+                 courant_number=None, dtype=np.float64):
+        self.dtype = np.dtype(dtype)
         self.grid_spacing = float(grid_spacing)
         self.Nx, self.Ny, self.Nz = (int(s) for s in shape)
         self.shape = (self.Nx, self.Ny, self.Nz)
@@ -523,10 +539,10 @@ class OracleGrid:
             self.courant_number = float(courant_number)
         self.time_step = self.courant_number * self.grid_spacing / C0
         full = (self.Nx, self.Ny, self.Nz, 3)
-        self.E = np.zeros(full)
-        self.H = np.zeros(full)
-        self.inverse_permittivity = np.ones(full) / float(permittivity)
-        self.inverse_permeability = np.ones(full) / float(permeability)
+        self.E = np.zeros(full, self.dtype)
+        self.H = np.zeros(full, self.dtype)
+        self.inverse_permittivity = np.ones(full, self.dtype) / float(permittivity)
+        self.inverse_permeability = np.ones(full, self.dtype) / float(permeability)
         self.time_steps_passed = 0
         self.sources, self.boundaries, self.detectors, self.objects = [], [], [], []
         # extension (not in the reference): x-slab ghost planes

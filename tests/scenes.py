@@ -262,6 +262,23 @@ SCENES["cc_point"] = dict(
     steps=35,
 )
 
+# PMLs on all six faces registered through the DomainBorderPML helper (reference
+# fdtd/boundaries.py:617-645: z faces first, then x, then y), as reference
+# tests/test_antenna_impedance.py:62 sets its domain up; 3-D only (the helper refuses grids
+# thinner than two borders along any axis).
+SCENES["border3d"] = dict(
+    grid=dict(shape=(23, 21, 19), permittivity=1.1),
+    items=[
+        ("border",    None, dict(border_cells=4)),
+        ("object",    (S(8, 15), S(2, 9), S(6, 12)), dict(permittivity=2.3)),          # reaches into the y-low PML
+        ("absorbing", (S(12, 18), S(10, 16), S(9, 14)), dict(permittivity=1.4, conductivity=3e4)),
+        ("point",     (10, 11, 8), dict(period=9)),
+        ("linedet",   (S(1, 22), 11, 9), {}),
+        ("currentdet", (11, 11, 8), {}),
+    ],
+    steps=60,
+)
+
 SLAB_SCENES = {
     "slab_mix": dict(
         grid=dict(shape=(26, 14, 12)),
@@ -471,6 +488,13 @@ def build_api(scene, fdtd, grid_factory=None):
         kind, key, kw = item[0], item[1], dict(item[2])
         extra = item[3] if len(item) > 3 else {}
         kw = {k: _materialise(v) for k, v in kw.items()}
+        if kind == "border":
+            # the helper registers six PMLs itself; they are listed like hand-made ones
+            helper = getattr(fdtd, "DomainBorderPML", None) or fdtd.boundaries.DomainBorderPML
+            before = len(grid.boundaries)
+            helper(grid, **kw)
+            made += [("pml", t, {}, {}) for t in grid.boundaries[before:]]
+            continue
         cls = {
             "pml": fdtd.PML, "periodic": fdtd.PeriodicBoundary, "object": fdtd.Object,
             "absorbing": fdtd.AbsorbingObject, "anisotropic": fdtd.AnisotropicObject,
@@ -651,13 +675,14 @@ def kw_no_name(kw):
     return {k: v for k, v in kw.items() if k != "name"}
 
 
-def build_oracle(resolved, arrays):
-    """Build the numpy oracle from a resolved description."""
+def build_oracle(resolved, arrays, dtype=np.float64):
+    """Build the numpy oracle from a resolved description (dtype=np.float32: its float32
+    twin, see oracle/yee_numpy.py)."""
     from oracle.yee_numpy import OracleGrid
 
     g = resolved["grid"]
     grid = OracleGrid(tuple(g["shape"]), grid_spacing=g["grid_spacing"],
-                      permittivity=g["permittivity"], permeability=g["permeability"])
+                      permittivity=g["permittivity"], permeability=g["permeability"], dtype=dtype)
     assert grid.courant_number == g["courant_number"]
     made = []
 

@@ -1,0 +1,311 @@
+"""Oracle parity at the benchmark's full size (512^3) and over 1000 steps.
+
+Light-cone crop.  Fields start at zero and only point sources drive them, so after N
+steps a source at cell s has reached the cells within N of s along every axis and nothing
+else (each half step looks one cell along each axis: reference fdtd/grid.py:29-76).  An
+oracle grid that holds just that window of the big grid -- the true domain faces the
+window touches with their PMLs, the parts of the objects inside it, the detector cells
+inside it -- therefore reproduces the big grid's fields inside the window exactly: at the
+window's cut faces every field value is still zero, so the one-sided difference rules of a
+grid edge (grid.py:42-49, 67-74) and of a PML slab edge (boundaries.py:437-444, 465-472)
+act on zeros either way.
+
+The scene is benchmark configuration 3 in kind and size (512^3, PML(10) on all six faces,
+a 64^3 anisotropic object with off-diagonal entries, a 64^3 absorbing object, three line
+detectors along x, y and z, point sources) with the components moved to where two sources
+reach them within N steps: one source near the low corner (x-, y-, z-low PMLs, the
+anisotropic object, which also overlaps the x-low PML), one near the high corner (the three
+high PMLs, the absorbing object).  The kernels' size-dependent logic -- object hull and
+PML-free core tests per wavefront, per-face index ranges, row-segment rotation, 64-bit
+offsets -- runs at its full-size values.
+
+Tolerances: float64 relative L2 <= 1e-12, float32 <= 1e-5, on E, H, both live memory
+variables of every PML face a cone reaches, and the detector rows; exact zeros outside the
+cones.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import fdtd_amd as fdtd
+from oracle import yee_numpy as orc
+from test_hip_parity import TOL, host, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+N_FULL = 512
+PML_T = 10
+STEPS = 24
+MARGIN = 2
+OFF_SEED = 3
+
+ANISO_BOX = (6, 70, 24, 88, 22, 86)          # overlaps the x-low PML slab (planes 0..9)
+ABSORB_BOX = (430, 494, 436, 500, 433, 497)
+SOURCES = ((15, 17, 14), (498, 496, 499))     # (cell, period 20 / 13)
+PERIODS = (20, 13)
+# line detectors along x, y, z: the first two cross the low cone, the third the high one
+DET_X = (slice(12, 500), 19, 16)
+DET_Y = (13, slice(12, 500), 18)
+DET_Z = (497, 495, slice(12, 500))
+
+
+def _window(src, n=N_FULL, reach=STEPS + MARGIN):
+    return tuple(v for c in src for v in (max(0, c - reach), min(n, c + reach + 1)))
+
+
+def _aniso_tensor():
+    """Full (64,64,64,3,3) tensor of the anisotropic object as the reference builds it:
+    1/permittivity on the diagonal, the far faces taking the grid's value (1.0) in the
+    component normal to them (reference fdtd/objects.py:60-88, 244-249), plus the
+    off-diagonal entries the scene adds."""
+    inv = np.ones((64, 64, 64, 3)) / 2.5
+    inv[-1, :, :, 0] = 1.0
+    inv[:, -1, :, 1] = 1.0
+    inv[:, :, -1, 2] = 1.0
+    full = np.zeros((64, 64, 64, 3, 3))
+    for c in range(3):
+        full[..., c, c] = inv[..., c]
+    off = 0.05 * np.random.RandomState(OFF_SEED).randn(64, 64, 64, 3, 3)
+    for c in range(3):
+        off[..., c, c] = 0
+    return full + off, off
+
+
+def _absorb_arrays(sc, spacing):
+    """inverse permittivity and absorption factor of the absorbing object (reference
+    fdtd/objects.py:188-202)."""
+    inv = np.ones((64, 64, 64, 3)) / 2.0
+    inv[-1, :, :, 0] = 1.0
+    inv[:, -1, :, 1] = 1.0
+    inv[:, :, -1, 2] = 1.0
+    f = 0.5 * sc * inv * 1e-3 * spacing * orc.ETA0
+    return inv, f
+
+
+def _engine_scene():
+    g = fdtd.Grid((N_FULL,) * 3)
+    for axis in range(3):
+        lo, hi = [slice(None)] * 3, [slice(None)] * 3
+        lo[axis], hi[axis] = slice(0, PML_T), slice(-PML_T, None)
+        g[tuple(lo)] = fdtd.PML()
+        g[tuple(hi)] = fdtd.PML()
+    for cell, period in zip(SOURCES, PERIODS):
+        g[cell] = fdtd.PointSource(period=period)
+    ani = fdtd.AnisotropicObject(permittivity=2.5)
+    b = ANISO_BOX
+    g[b[0]:b[1], b[2]:b[3], b[4]:b[5]] = ani
+    with torch.no_grad():
+        ani.inverse_permittivity += fdtd.backend.array(_aniso_tensor()[1])
+    b = ABSORB_BOX
+    g[b[0]:b[1], b[2]:b[3], b[4]:b[5]] = fdtd.AbsorbingObject(permittivity=2.0, conductivity=1e-3)
+    dets = []
+    for key in (DET_X, DET_Y, DET_Z):
+        d = fdtd.LineDetector()
+        g[key] = d
+        dets.append(d)
+    return g, dets
+
+
+def _clip(box, win):
+    out = []
+    for a in range(3):
+        lo, hi = max(box[2 * a], win[2 * a]), min(box[2 * a + 1], win[2 * a + 1])
+        if hi <= lo:
+            return None
+        out += [lo, hi]
+    return tuple(out)
+
+
+def _det_cells(key):
+    """Global cells of a line detector given as (slice | int) x 3."""
+    n = max((k.stop - k.start) for k in key if isinstance(k, slice))
+    cols = []
+    for k in key:
+        cols.append(list(range(k.start, k.stop)) if isinstance(k, slice) else [k] * n)
+    return np.array(cols).T      # (n, 3)
+
+
+def _oracle_window(win, src, period, sc):
+    """The oracle on the window `win` of the big grid: returns the grid, its PMLs keyed by
+    (axis, side), and per detector (point mask, oracle detector)."""
+    shape = tuple(win[2 * a + 1] - win[2 * a] for a in range(3))
+    o = orc.OracleGrid(shape)
+    assert o.courant_number == sc
+    pmls = {}
+    for axis in range(3):                       # the engine's registration order, restricted
+        if win[2 * axis] == 0:
+            pmls[(axis, "low")] = o.add_pml(axis, "low", PML_T)
+        if win[2 * axis + 1] == N_FULL:
+            pmls[(axis, "high")] = o.add_pml(axis, "high", PML_T)
+    o.add_point_source(tuple(c - win[2 * a] for a, c in enumerate(src)), period=period)
+    for kind, box in (("anisotropic", ANISO_BOX), ("absorbing", ABSORB_BOX)):
+        cb = _clip(box, win)
+        if cb is None:
+            continue
+        local = tuple(cb[n] - win[2 * (n // 2)] for n in range(6))
+        part = tuple(slice(cb[2 * a] - box[2 * a], cb[2 * a + 1] - box[2 * a]) for a in range(3))
+        if kind == "anisotropic":
+            ob = o.add_object(local, 2.5, kind="anisotropic")
+            ob.inverse_permittivity = _aniso_tensor()[0][part].copy()
+        else:
+            ob = o.add_object(local, 2.0, kind="absorbing", conductivity=1e-3)
+            inv, f = _absorb_arrays(sc, o.grid_spacing)
+            ob.inverse_permittivity, ob.absorption_factor = inv[part].copy(), f[part].copy()
+    dets = []
+    for key in (DET_X, DET_Y, DET_Z):
+        cells = _det_cells(key)
+        inside = np.all([(cells[:, a] >= win[2 * a]) & (cells[:, a] < win[2 * a + 1]) for a in range(3)], axis=0)
+        loc = cells[inside] - np.array([win[0], win[2], win[4]])
+        dets.append((inside, o.add_line_detector(list(loc[:, 0]), list(loc[:, 1]), list(loc[:, 2]))))
+    return o, pmls, dets
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_benchmark_scene_at_512_cubed_matches_the_oracle_inside_the_light_cones(dtype):
+    fdtd.set_backend(f"hip.{dtype}")
+    tol = TOL[dtype]
+    g, dets = _engine_scene()
+    g.run(STEPS, progress_bar=False)
+    torch.cuda.synchronize()
+    from fdtd_amd import _lib
+    assert _lib.load().fdtdhip_plan_scan_materials(g._plan, 1) == 3   # the benchmark's kernel path
+    engine_pml = {}
+    for b in g.boundaries:
+        engine_pml[(b.axis, "low" if b._lo == 0 else "high")] = b
+    seen = [np.zeros(len(_det_cells(k)), bool) for k in (DET_X, DET_Y, DET_Z)]
+    outside_E, outside_H = g.E.clone(), g.H.clone()
+    for src, period in zip(SOURCES, PERIODS):
+        win = _window(src)
+        o, pmls, odets = _oracle_window(win, src, period, g.courant_number)
+        o.run(STEPS)
+        w = tuple(slice(win[2 * a], win[2 * a + 1]) for a in range(3))
+        assert np.abs(o.E).max() > 0
+        # the cut faces of the window are still untouched
+        for a in range(3):
+            for side, edge in ((0, win[2 * a] > 0), (-1, win[2 * a + 1] < N_FULL)):
+                if edge:
+                    assert np.abs(np.take(o.E, side, axis=a)).max() == 0
+                    assert np.abs(np.take(o.H, side, axis=a)).max() == 0
+        assert rel_l2(host(g.E[w]), o.E) <= tol, ("E", src)
+        assert rel_l2(host(g.H[w]), o.H) <= tol, ("H", src)
+        outside_E[w] = 0
+        outside_H[w] = 0
+        assert len(pmls) == 3
+        for (axis, side), ob in pmls.items():
+            b = engine_pml[(axis, side)]
+            u, v = (axis + 1) % 3, (axis + 2) % 3
+            sl = [slice(None)] + [slice(win[2 * a], win[2 * a + 1]) for a in range(3)]
+            sl[1 + axis] = slice(None)            # the whole thickness of the slab
+            for mine, fam in ((b._psiE, ob.psi_E), (b._psiH, ob.psi_H)):
+                want = np.stack([fam[u][..., axis], fam[v][..., axis]])
+                assert np.abs(want).max() > 0, ("the cone reaches this face", axis, side)
+                assert rel_l2(host(mine[tuple(sl)]), want) <= tol, ("psi", axis, side, src)
+        for n, ((inside, od), d) in enumerate(zip(odets, dets)):
+            if not inside.any():
+                continue
+            idx = torch.as_tensor(np.nonzero(inside)[0], device=g.E.device)
+            for mine, want in ((d.E, od.E), (d.H, od.H)):
+                got = host(torch.stack(list(mine))[:, idx])
+                want = np.array(want)
+                if np.abs(want).max() > 0:
+                    assert rel_l2(got, want) <= tol, ("detector", n, src)
+                else:
+                    assert np.abs(got).max() == 0
+            seen[n] |= inside
+    # nothing anywhere else: fields, and the detector points no cone reaches
+    assert float(outside_E.abs().max()) == 0 and float(outside_H.abs().max()) == 0
+    for n, d in enumerate(dets):
+        assert seen[n].any(), "every detector crosses a cone"
+        rest = torch.as_tensor(np.nonzero(~seen[n])[0], device=g.E.device)
+        assert float(torch.stack(list(d.E))[:, rest].abs().max()) == 0
+
+
+_LONG = {}
+
+
+def _long_oracle(shape, steps, dtype=np.float64):
+    """1000 oracle steps take about a minute: run once per precision."""
+    key = np.dtype(dtype).name
+    if key not in _LONG:
+        o = orc.OracleGrid(shape, dtype=dtype)
+        for axis in range(3):
+            o.add_pml(axis, "low", 6)
+            o.add_pml(axis, "high", 6)
+        o.add_object((10, 22, 12, 30, 9, 20), 2.2)
+        oa = o.add_object((26, 36, 14, 26, 24, 38), 1.9, kind="anisotropic")
+        oa.inverse_permittivity += _long_off().astype(dtype)
+        o.add_object((12, 30, 32, 40, 26, 36), 1.6, kind="absorbing", conductivity=5e-3)
+        o.add_point_source((24, 22, 21), period=19)
+        od = o.add_line_detector(list(range(8, 40)), [24] * 32, [23] * 32)
+        oc = o.add_current_detector([23], [21], [22])
+        o.run(steps)
+        _LONG[key] = (o, od, oc)
+    return _LONG[key]
+
+
+def _long_off():
+    off = 0.03 * np.random.RandomState(8).randn(10, 12, 14, 3, 3)
+    for c in range(3):
+        off[..., c, c] = 0
+    return off
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_thousand_steps_against_the_oracle(dtype):
+    """The length of benchmark configuration 2 (1000 steps) on a 48^3 grid the oracle can
+    follow: six PMLs, the three object kinds, a point source, a line and a loop-current
+    detector.
+
+    float64: relative L2 <= 1e-12 on the final fields and the whole detector records.
+    float32: rounding errors accumulate over 1000 steps: the oracle's own float32 twin
+    (same arithmetic on float32 arrays) ends 4e-5 from the float64 run.  The engine is
+    held to 1e-5 against that twin, and to 1e-4 against float64."""
+    fdtd.set_backend(f"hip.{dtype}")
+    shape, steps = (48, 46, 44), 1000
+    o, od, oc = _long_oracle(shape, steps)
+    g = fdtd.Grid(shape)
+    for axis in range(3):
+        lo, hi = [slice(None)] * 3, [slice(None)] * 3
+        lo[axis], hi[axis] = slice(0, 6), slice(-6, None)
+        g[tuple(lo)] = fdtd.PML()
+        g[tuple(hi)] = fdtd.PML()
+    g[10:22, 12:30, 9:20] = fdtd.Object(permittivity=2.2)
+    ani = fdtd.AnisotropicObject(permittivity=1.9)
+    g[26:36, 14:26, 24:38] = ani
+    with torch.no_grad():
+        ani.inverse_permittivity += fdtd.backend.array(_long_off())
+    g[12:30, 32:40, 26:36] = fdtd.AbsorbingObject(permittivity=1.6, conductivity=5e-3)
+    g[24, 22, 21] = fdtd.PointSource(period=19)
+    det, cur = fdtd.LineDetector(), fdtd.CurrentDetector()
+    g[8:40, 24, 23] = det
+    g[23, 21, 22] = cur
+    g.run(steps, progress_bar=False)
+    torch.cuda.synchronize()
+    assert g.time_steps_passed == steps
+    assert np.isfinite(o.E).all() and np.abs(o.E).max() > 0
+    currents = host(cur.I).reshape(steps)
+    if dtype == "float64":
+        tol = TOL[dtype]
+        assert rel_l2(host(g.E), o.E) <= tol
+        assert rel_l2(host(g.H), o.H) <= tol
+        assert rel_l2(host(det.E), np.array(od.E)) <= tol
+        assert rel_l2(host(det.H), np.array(od.H)) <= tol
+        assert rel_l2(currents, np.array(oc.I).reshape(steps)) <= tol
+        return
+    t, td, tc = _long_oracle(shape, steps, np.float32)
+    report = {}
+    for name, got, twin, want in (("E", host(g.E), t.E, o.E), ("H", host(g.H), t.H, o.H),
+                                  ("detector E", host(det.E), np.array(td.E), np.array(od.E)),
+                                  ("detector H", host(det.H), np.array(td.H), np.array(od.H))):
+        report[name] = (rel_l2(got, twin), rel_l2(got, want), rel_l2(twin, want))
+    print("float32 after 1000 steps (engine-twin, engine-float64, twin-float64):",
+          {k: tuple(f"{x:.2e}" for x in v) for k, v in report.items()})
+    for name, (to_twin, to_f64, _) in report.items():
+        assert to_twin <= 1e-5, (name, "engine against the float32 twin", to_twin)
+        assert to_f64 <= 1e-4, (name, "engine against float64", to_f64)
+    # a loop current is a sum of differences of nearly equal H values: its float32 error is
+    # set by the rounding of H, so it is measured on the scale of H x cell size
+    scale = np.abs(o.H).max() * o.grid_spacing
+    twin_I = np.array(tc.I, dtype=np.float64).reshape(steps)
+    assert np.abs(currents - twin_I).max() <= 1e-5 * max(scale, np.abs(twin_I).max())

@@ -1,10 +1,24 @@
 """Seeded random scenes (tests/fuzz_scenes.py) on the HIP engine against the numpy oracle.
 
 The same generator, run through the real reference where its checkout exists
-(tools/fuzz_reference.py), showed the oracle bitwise equal to the reference on 720 scenes;
-here the engine has to match the oracle on a spread of them: float64 to 1e-12, float32 to
-1e-5 (relative L2 of E, H and every detector trace; the live PML memory variables
-to 1e-12 in float64 only, loop currents to 1e-3 in float32).
+(tools/fuzz_reference.py), showed the oracle bitwise equal to the reference on 800 scenes;
+here the engine has to match the oracle on a spread of them.
+
+float64: relative L2 <= 1e-12 on E, H, every detector record, loop currents and the live PML
+memory variables.
+
+float32: the reference has no float32 trajectory, so the engine is held against two things:
+the float64 oracle at 1e-5 (E, H, field detectors), and the oracle's float32 twin -- the same
+slice algebra on float32 arrays (oracle/yee_numpy.py) -- at 1e-5 on every quantity.  On
+750 random scenes (tools/fuzz_fp32_twin.py) engine and twin agree bit for bit on 70 % of the
+field quantities and to 3.6e-6 at worst, while the twin itself is up to 1.5e-5 from float64
+on a handful of scenes (dozens of overlapping objects, 1-D grids at the stability limit):
+float32 rounding of the reference's own arithmetic, not a property of the kernels.  A field
+quantity may therefore exceed 1e-5 against float64 only where the twin is as far away.
+Loop currents and PML memory variables are sums of differences of nearly equal field values;
+their float32 error is set by the size of those field values, so they are compared with the
+twin on that scale: max |difference| <= 1e-5 x (largest field value involved), or 1e-5
+relative L2.
 """
 import os
 import sys
@@ -23,13 +37,6 @@ import scenes  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 TOL = {"float64": 1e-12, "float32": 1e-5}
-# float32 only: PML memory variables and loop currents are built from differences of
-# neighbouring field values; where a field is (nearly) uniform along the direction of the
-# difference they are rounding noise in both precisions and their relative error means
-# nothing (600 scenes: up to 0.3 for a memory variable, 4e-4 for a loop current, while E,
-# H and the field detectors they feed stay within 1e-5).  Float32 therefore checks the loop
-# currents to 1e-3 and leaves the memory variables to the float64 runs.
-DIFF_TOL = {"float64": 1e-12, "float32": 1e-3}
 
 def host(t):
     if isinstance(t, (list, tuple)):
@@ -51,14 +58,41 @@ def live_psi(ot):
                      ot.psi_H[u][..., ot.axis], ot.psi_H[v][..., ot.axis]])
 
 
+def _records(made, grid):
+    """name -> float64 array of everything a scene produced, engine or oracle side."""
+    out = {"E": host(grid.E), "H": host(grid.H)}
+    for n, entry in enumerate(made):
+        kind, t = entry[0], entry[1]
+        if kind == "pml":
+            out[f"psi{n}"] = (np.concatenate([host(t._psiE), host(t._psiH)]) if hasattr(t, "_psiE")
+                              else live_psi(t))
+        elif kind in ("linedet", "blockdet"):
+            out[f"det{n}_E"], out[f"det{n}_H"] = host(t.E), host(t.H)
+        elif kind == "currentdet":
+            out[f"det{n}_I"] = host(t.I)
+        elif kind == "soft":   # both voltage records and the loop current that feeds back
+            out[f"src{n}_vin"], out[f"src{n}_vout"] = host(t.input_voltage), host(t.source_voltage)
+            out[f"src{n}_I"] = host(t.current_detector.I)
+    return {k: np.asarray(v, dtype=np.float64).reshape(-1) for k, v in out.items()}
+
+
+def _is_difference_quantity(name):
+    return name.endswith("_I") or name.startswith("psi")
+
+
 def check_scene(seed, dtype, big=False, extras=False, substrate=False, crowded=False):
+    """Returns (dict of quantities out of tolerance, scene), or None for a scene whose
+    oracle run is not finite."""
     fdtd.set_backend(f"hip.{dtype}")
     scene = (fuzz_scenes.random_substrate_scene(seed) if substrate
              else fuzz_scenes.random_scene(seed, big=big, extras=extras, crowded=crowded))
     grid, made = scenes.build_api(scene, fdtd)
     resolved, arrays = scenes.resolve(scene, grid, made)
     ogrid, omade = scenes.build_oracle(resolved, arrays)
-    errs = {"inv_eps": rel_l2(host(grid.inverse_permittivity), ogrid.inverse_permittivity)}
+    bad = {}
+    err = rel_l2(host(grid.inverse_permittivity), ogrid.inverse_permittivity)
+    if not err <= TOL[dtype]:
+        bad["inv_eps"] = err
     with torch.no_grad() if substrate and seed % 2 else torch.enable_grad():
         # (a substrate tensor requires grad: half of those scenes run as recorded runs)
         scenes.run_scene(scene, grid)
@@ -66,26 +100,57 @@ def check_scene(seed, dtype, big=False, extras=False, substrate=False, crowded=F
     torch.cuda.synchronize()
     if not np.isfinite(ogrid.E).all():
         return None
-    errs["E"], errs["H"] = rel_l2(host(grid.E), ogrid.E), rel_l2(host(grid.H), ogrid.H)
-    for n, ((kind, t, _, _), (_, ot)) in enumerate(zip(made, omade)):
-        if kind == "pml":
-            errs[f"psi{n}"] = rel_l2(np.concatenate([host(t._psiE), host(t._psiH)]), live_psi(ot))
-        elif kind in ("linedet", "blockdet"):
-            errs[f"det{n}_E"] = rel_l2(host(t.E), np.array(ot.E))
-            errs[f"det{n}_H"] = rel_l2(host(t.H), np.array(ot.H))
-        elif kind == "currentdet":
-            errs[f"det{n}_I"] = rel_l2(host(t.I), np.array(ot.I))
-        elif kind == "soft":   # both voltage records and the loop current that feeds back
-            errs[f"src{n}_vin"] = rel_l2(host(t.input_voltage), np.array(ot.input_voltage, dtype=np.float64))
-            errs[f"src{n}_vout"] = rel_l2(host(t.source_voltage), np.array(ot.source_voltage, dtype=np.float64))
-            errs[f"src{n}_I"] = rel_l2(host(t.current_detector.I), np.array(ot.current_detector.I))
-    if dtype == "float32":
-        errs = {k: v for k, v in errs.items() if not k.startswith("psi")}
-    return {k: v for k, v in errs.items()
-            if not v <= (DIFF_TOL if k.endswith("_I") or k.startswith("psi") else TOL)[dtype]}, scene
+    got, want = _records(made, grid), _records(omade, ogrid)
+    if dtype == "float64":
+        for k in want:
+            err = rel_l2(got[k], want[k])
+            if not err <= TOL[dtype]:
+                bad[k] = err
+        return bad, scene
+    # float32: the twin runs the same scene on float32 arrays
+    tgrid, tmade = scenes.build_oracle(resolved, arrays, dtype=np.float32)
+    scenes.run_oracle(resolved, tgrid)
+    twin = _records(tmade, tgrid)
+    field_scale = max(np.abs(want["E"]).max(), np.abs(want["H"]).max())
+    for k in want:
+        to_twin, to_f64, twin_to_f64 = rel_l2(got[k], twin[k]), rel_l2(got[k], want[k]), rel_l2(twin[k], want[k])
+        if _is_difference_quantity(k):
+            scale = field_scale * (ogrid.grid_spacing if k.endswith("_I") else 1.0)
+            if not (to_twin <= 1e-5 or np.abs(got[k] - twin[k]).max() <= 1e-5 * scale):
+                bad[k] = dict(engine_twin=to_twin, max_abs=float(np.abs(got[k] - twin[k]).max()), scale=scale)
+            continue
+        if not to_twin <= 1e-5:
+            bad[k] = dict(engine_twin=to_twin)
+        elif not (to_f64 <= 1e-5 or twin_to_f64 >= 0.5 * to_f64):
+            bad[k] = dict(engine_f64=to_f64, twin_f64=twin_to_f64)
+    return bad, scene
 
 
-@pytest.mark.parametrize("dtype,seeds", [("float64", range(0, 60)), ("float32", range(60, 80))])
+# float32 scenes that are more than 1e-5 away from float64 (twin and engine alike): two 1-D
+# grids at the stability limit, two crowded scenes
+FLOAT32_INHERENT = ((236, {}), (552, {}), (3084, dict(extras=True, crowded=True)),
+                    (3142, dict(extras=True, crowded=True)))
+
+
+def test_float32_scenes_far_from_float64_are_the_twins_rounding_not_the_kernels():
+    bad = {}
+    for seed, kw in FLOAT32_INHERENT:
+        out = check_scene(seed, "float32", **kw)
+        if out and out[0]:
+            bad[seed] = out
+    assert not bad, f"float32 engine differs from the float32 twin: {bad}"
+
+
+def test_random_crowded_scenes_float32_match_twin_and_oracle():
+    bad = {}
+    for seed in range(3040, 3070):
+        out = check_scene(seed, "float32", extras=True, crowded=True)
+        if out and out[0]:
+            bad[seed] = out
+    assert not bad, f"float32 crowded scenes: {bad}"
+
+
+@pytest.mark.parametrize("dtype,seeds", [("float64", range(0, 60)), ("float32", range(60, 180))])
 def test_random_scenes_match_oracle(dtype, seeds):
     bad = {}
     for seed in seeds:
