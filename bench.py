@@ -6,35 +6,42 @@ Prints ONE JSON line (rank 0).  A "step" is one full Yee step (E half step + H
 half step) of the whole grid; `value` is cell-updates per second summed over all
 GPUs with the fields resident in HBM.
 
-Workloads (all synthetic, fields start at zero, a point source drives them):
-  m3v   512^3 float32, vacuum, PointSource            (default: the "512^3 float32
-        Yee update" the headline metric is quoted on)
+Workloads (all synthetic, fields start at small random values, a point source drives them):
+  m3v   512^3 float32, vacuum, PointSource            (default for one GPU: the "512^3
+        float32 Yee update" the headline metric is quoted on)
   m3    512^3 float32, 6 PML(10), anisotropic + absorbing objects, 3 LineDetectors
   m2    256^3 float64, 6 PML(10), PointSource
+  m3v64 512^3 float64, vacuum, PointSource
   c1    161x97x1 float64, the reference's README example
-  m4    256x1024x1024 float32 per GPU, 6 PML(10), PointSource: with --gpus 8 the
-        2048x1024x1024 x-slab configuration
-With --gpus N > 1 the grid is N slabs of the single-GPU size along x (weak
-scaling), one process per GPU, halo planes exchanged over RCCL.
+  m4    256x1024x1024 float32 per GPU, 6 PML(10), PointSource (default for N > 1: with
+        --gpus 8 the 2048x1024x1024 x-slab configuration)
+With --gpus N > 1 the grid is N slabs of the single-GPU size along x (weak scaling), one
+process per GPU, the two tangential components of one halo plane exchanged per half step
+over RCCL.  Started as a plain `python bench.py --gpus N` the script launches its N ranks
+itself (`python -m torch.distributed.run`, as child processes, before anything touches a
+GPU) and relays rank 0's line; started by torch.distributed.run it is one of the ranks.
 
 Materials: the grids are homogeneous outside their objects, as the reference creates
 them, and the library then passes the material arrays to its kernels as constants
 (it proves this with a scan whenever the arrays change).  `roofline` counts only the
 bytes the kernels then have to move.  --materials arrays turns the feature off (every
-kernel reads both material arrays); --also-arrays adds that measurement to the line as
-`array_materials`.
+kernel reads both material arrays).
 
 Extra objects in the JSON line:
   roofline      achieved algorithmic GB/s of the bulk kernels from HIP-event
                 timings taken inside the timed region, against the 8 TB/s HBM peak
   cpu_baseline  the numpy oracle (a restatement of the reference's numpy backend)
-                timed on this machine's host cores on a bounded sample
+                timed on this machine's host cores on bounded samples (128^3 and 256^3)
+  also          (one GPU, default workload, unless --no-also) the other benchmark
+                configurations measured by the same run: the headline grid with both material
+                arrays read, the headline grid over 1000 steps ("sustained"), m3, m2, m3v64
 """
 
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -42,10 +49,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (spec)
+PMC_NOTE = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this workload, not this run)"
 
 
 def build_workload(fdtd, name, n_slabs=1, rank=0, group=None):
-    """Returns (grid, cells_per_rank, bytes_per_cell_step, dtype label, description)."""
+    """Returns (grid, cells_per_rank, element size, dtype label, description)."""
     import numpy as np
     import torch
 
@@ -58,6 +66,9 @@ def build_workload(fdtd, name, n_slabs=1, rank=0, group=None):
     elif name == "m2":
         fdtd.set_backend("hip.float64")
         shape, es, dt = (256, 256, 256), 8, "f64"
+    elif name == "m3v64":
+        fdtd.set_backend("hip.float64")
+        shape, es, dt = (512, 512, 512), 8, "f64"
     elif name == "c1":
         fdtd.set_backend("hip.float64")
         shape, es, dt = (161, 97, 1), 8, "f64"
@@ -71,7 +82,7 @@ def build_workload(fdtd, name, n_slabs=1, rank=0, group=None):
         grid = fdtd.Grid(shape)
     nx, ny, nz = grid.Nx_global, grid.Ny, grid.Nz  # extents of the whole simulation
     desc = f"{nx}x{ny}x{nz} {dt}"
-    if name == "m3v":
+    if name in ("m3v", "m3v64"):
         grid[nx // 2, ny // 2, nz // 2] = fdtd.PointSource(period=20)
         desc += " vacuum + PointSource"
     elif name in ("m2", "m4"):
@@ -162,38 +173,130 @@ def use_material_arrays(grid, lib, _lib):
     _lib.check(lib.fdtdhip_plan_scan_materials(grid._plan, 0))
 
 
-def cpu_baseline(name, budget_s=15.0):
-    """The numpy oracle on a bounded sample of the same scene (rank 0, N=1 only)."""
+def roofline(grid, cells, es, ms_e, ms_h, mask, steps, workload):
+    """The dominant kernel is the bulk half-step kernel.  One half step of one GPU = `cells`
+    cells = one bulk launch on a single GPU; on a slab it is two launches (interior planes,
+    then the plane that waits for the halo), so durations are summed per half step before
+    dividing."""
+    be, bh = half_step_bytes(grid, cells, es, mask)
+    avg_ms = (ms_e + ms_h) / (2 * steps)
+    per_launch = (be + bh) / 2
+    achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roof = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
+        "kernel": "bulk half-step kernel (E and H)",
+        "materials": {0: "arrays", 1: "inverse permittivity constant", 2: "inverse permeability constant",
+                      3: "constants"}[mask],
+        "bytes_per_launch": per_launch,
+        # the same duration priced at 12 values per cell and half step whatever the
+        # materials are (every array counted as read): an effective rate, not HBM traffic
+        "all_arrays_equivalent_GBps": round(cells * 12 * es / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
+        "avg_launch_ms": round(avg_ms, 4),
+        "avg_launch_ms_E": round(ms_e / steps, 4),
+        "avg_launch_ms_H": round(ms_h / steps, 4),
+    }
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc)).get(f"{workload}:{roof['materials']}")
+        if rec:
+            roof["traffic"] = rec.get("bytes_per_launch")
+            roof["traffic_source"] = PMC_NOTE
+    return roof
+
+
+def measure_single(workload, steps, warmup, materials="auto"):
+    """One workload on this process's GPU; returns a compact record and releases the grid."""
+    import torch
+
+    import fdtd_amd as fdtd
+    from fdtd_amd import _lib
+
+    lib = _lib.load()
+    grid, cells, es, dt, desc = build_workload(fdtd, workload)
+    if materials == "arrays":
+        use_material_arrays(grid, lib, _lib)
+    with torch_no_grad():
+        grid.run(warmup, progress_bar=False)
+    torch.cuda.synchronize()
+    mask = 0 if materials == "arrays" else _lib.check(lib.fdtdhip_plan_scan_materials(grid._plan, 1))
+    elapsed, msE, nE, msH, nH = timed_run(grid, lib, _lib, steps, torch.cuda.synchronize)
+    roof = roofline(grid, cells, es, msE, msH, mask, steps, workload)
+    rec = {
+        "workload": desc, "name": workload, "dtype": dt, "steps": steps, "warmup": warmup,
+        "value": round(cells * steps / elapsed / 1e9, 3), "unit": "Gcells/s",
+        "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "avg_launch_ms": roof["avg_launch_ms"], "achieved": roof["achieved"], "frac": roof["frac"],
+        "materials": roof["materials"], "bytes_per_launch": roof["bytes_per_launch"],
+        "traffic": roof["traffic"],
+    }
+    del grid
+    torch.cuda.empty_cache()
+    return rec
+
+
+def cpu_baseline(name, budget_s=12.0):
+    """The numpy oracle on bounded samples of the same scene (rank 0, N=1 only): 128^3 for
+    about `budget_s` seconds, then 256^3 for 5 steps."""
     from oracle.yee_numpy import OracleGrid  # CPU baseline leg: allowed use of the oracle
 
+    def sample(shape, budget, min_steps, max_steps):
+        g = OracleGrid(shape)
+        if name in ("m2", "m3", "m4"):
+            for axis in range(3):
+                g.add_pml(axis, "low", 10)
+                g.add_pml(axis, "high", 10)
+        if name == "c1":
+            for axis in range(2):
+                g.add_pml(axis, "low", 10)
+                g.add_pml(axis, "high", 10)
+            g.add_object((11, 32, 30, 84, 0, 1), 1.7 ** 2)
+        g.add_point_source((shape[0] // 2, shape[1] // 2, shape[2] // 2), period=20)
+        g.step()  # warm-up
+        t0, steps = time.perf_counter(), 0
+        while steps < min_steps or (time.perf_counter() - t0 < budget and steps < max_steps):
+            g.step()
+            steps += 1
+        dt = time.perf_counter() - t0
+        cells = shape[0] * shape[1] * shape[2]
+        return cells * steps / dt / 1e9, steps, dt
+
     if name == "c1":
-        n, shape = 1, (161, 97, 1)
+        v, steps, dt = sample((161, 97, 1), budget_s, 1, 2000)
+        shape_txt, extra = "161x97x1", {}
     else:
-        n, shape = 128, (128, 128, 128)
-    g = OracleGrid(shape)
-    if name in ("m2", "m3", "m4"):
-        for axis in range(3):
-            g.add_pml(axis, "low", 10)
-            g.add_pml(axis, "high", 10)
-    if name == "c1":
-        for axis in range(2):
-            g.add_pml(axis, "low", 10)
-            g.add_pml(axis, "high", 10)
-        g.add_object((11, 32, 30, 84, 0, 1), 1.7 ** 2)
-    g.add_point_source((shape[0] // 2, shape[1] // 2, shape[2] // 2), period=20)
-    g.step()  # warm-up
-    t0, steps = time.perf_counter(), 0
-    while time.perf_counter() - t0 < budget_s and steps < 2000:
-        g.step()
-        steps += 1
-    dt = time.perf_counter() - t0
-    cells = shape[0] * shape[1] * shape[2]
+        v, steps, dt = sample((128, 128, 128), budget_s, 1, 2000)
+        shape_txt = "128x128x128"
+        v2, steps2, dt2 = sample((256, 256, 256), 0.0, 5, 5)
+        extra = {"at_256": {"value": v2, "unit": "Gcells/s",
+                            "sample": f"256x256x256 cells, {steps2} steps in {dt2:.1f} s"}}
     return dict(
-        value=cells * steps / dt / 1e9, unit="Gcells/s", cores=1, kind="port",
-        sample=f"numpy float64 oracle, {shape[0]}x{shape[1]}x{shape[2]} cells, same boundaries and "
+        value=v, unit="Gcells/s", cores=1, kind="port",
+        sample=f"numpy float64 oracle, {shape_txt} cells, same boundaries and "
                f"source, {steps} steps in {dt:.1f} s (numpy elementwise ops use one core; "
-               f"host has {os.cpu_count()} logical CPUs)",
-    )
+               f"host has {os.cpu_count()} logical CPUs)", **extra)
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes
+    through torch.distributed.run and relay rank 0's JSON line.  Nothing in this process
+    has touched a GPU (torch is not even imported)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:
+        if line.lstrip().startswith("{"):
+            print(line.rstrip("\n"), flush=True)
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
 
 
 def main():
@@ -201,12 +304,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="m3v")
+    ap.add_argument("--workload", default=None, help="default: m3v on one GPU, m4 slabs on several")
     ap.add_argument("--materials", choices=("auto", "arrays"), default="auto")
-    ap.add_argument("--also-arrays", action="store_true",
-                    help="add an array_materials object: the same run with both material arrays read")
+    ap.add_argument("--no-also", action="store_true",
+                    help="leave out the `also` records (other configurations, sustained run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
 
@@ -214,7 +320,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    default_run = args.workload is None
+    workload = args.workload or ("m3v" if world == 1 else "m4")
     # one rank per GPU; FDTD_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals
     backend = os.environ.get("FDTD_DIST_BACKEND", "nccl")
     device = local_rank % torch.cuda.device_count()
@@ -262,7 +370,6 @@ def main():
     import fdtd_amd as fdtd
     from fdtd_amd import _lib
 
-    grid, cells, es, dt, desc = build_workload(fdtd, args.workload, world, rank, data_group)
     lib = _lib.load()
 
     def sync():
@@ -278,37 +385,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
         return float(t.item())
 
-    def roofline(ms_e, ms_h, mask, steps):
-        # dominant kernel: the bulk half-step kernel.  One half step of one GPU = `cells`
-        # cells = one bulk launch on a single GPU; on a slab it is two launches (interior
-        # planes, then the plane that waits for the halo), so durations are summed per
-        # half step before dividing.
-        be, bh = half_step_bytes(grid, cells, es, mask)
-        avg_ms = (ms_e + ms_h) / (2 * steps)
-        per_launch = (be + bh) / 2
-        achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        return {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-            "kernel": "bulk half-step kernel (E and H)",
-            "materials": {0: "arrays", 1: "inverse permittivity constant", 2: "inverse permeability constant",
-                          3: "constants"}[mask],
-            "bytes_per_launch": per_launch,
-            # the same duration priced at 12 values per cell and half step whatever the
-            # materials are (every array counted as read): an effective rate, not HBM traffic
-            "all_arrays_equivalent_GBps": round(cells * 12 * es / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
-            "avg_launch_ms": round(avg_ms, 4),
-            "avg_launch_ms_E": round(ms_e / steps, 4),
-            "avg_launch_ms_H": round(ms_h / steps, 4),
-        }
+    # on several GPUs rank 0 first times ONE slab of the same workload on its own (the other
+    # ranks wait): the per-GPU rate the N-slab value divides by for a scaling efficiency
+    one_slab = None
+    if world > 1:
+        if rank == 0 and workload != "c1":
+            one_slab = measure_single(workload, args.steps, args.warmup, args.materials)
+        sync()
 
+    grid, cells, es, dt, desc = build_workload(fdtd, workload, world, rank, data_group)
     if args.materials == "arrays":
         use_material_arrays(grid, lib, _lib)
     with torch_no_grad():
         grid.run(args.warmup, progress_bar=False)
     sync()
     mask = 0 if args.materials == "arrays" else _lib.check(lib.fdtdhip_plan_scan_materials(grid._plan, 1))
-    if args.workload == "c1":
+    if workload == "c1":
         # launch-bound: the step rate is timed without per-launch events, the kernel
         # durations come from a second pass of the same steps with them
         elapsed = timed_run(grid, lib, _lib, args.steps, sync, events=False)[0]
@@ -320,39 +412,37 @@ def main():
     out = None
     if rank == 0:
         value = cells * world * args.steps / elapsed / 1e9
-        roof = roofline(msE, msH, mask, args.steps)
+        roof = roofline(grid, cells, es, msE, msH, mask, args.steps, workload)
         roof["launches"] = nE + nH
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            rec = json.load(open(pmc)).get(f"{args.workload}:{roof['materials']}")
-            if rec:
-                roof["traffic"] = rec.get("bytes_per_launch")
         out = {
             "metric": "Yee cell-updates/s", "value": round(value, 3), "unit": "Gcells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
-            "config": {"workload": desc, "name": args.workload,
+            "config": {"workload": desc, "name": workload,
                        "parallelism": f"x-slab x{world}" if world > 1 else "single GPU",
-                       "cells_per_gpu": cells, **({"transport": transport} if transport else {})},
+                       "cells_per_gpu": cells,
+                       **({"transport": transport,
+                           "halo": f"{grid.Ny}x{grid.Nz}x2 {dt} per half step and neighbour"} if transport else {})},
             "roofline": roof,
         }
-    if mask and world == 1 and args.also_arrays:
-        # the same grid with every kernel reading both material arrays
-        use_material_arrays(grid, lib, _lib)
-        with torch_no_grad():
-            grid.run(args.warmup, progress_bar=False)
-        sync()
-        el2, e2, _, h2, _ = timed_run(grid, lib, _lib, args.steps, sync)
-        r2 = roofline(e2, h2, 0, args.steps)
-        out["array_materials"] = {
-            "value": round(cells * args.steps / el2 / 1e9, 3), "unit": "Gcells/s",
-            "ms_per_step": round(el2 / args.steps * 1e3, 4),
-            "achieved": r2["achieved"], "frac": r2["frac"], "bytes_per_launch": r2["bytes_per_launch"],
-        }
+        if one_slab is not None:
+            out["one_gpu_same_slab"] = one_slab
+    del grid
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and default_run and not args.no_also:
+        # the other benchmark configurations, measured by this same run
+        also = {}
+        also["array_materials"] = measure_single("m3v", args.steps, args.warmup, "arrays")
+        also["sustained"] = measure_single("m3v", 1000, args.warmup)
+        also["m3"] = measure_single("m3", 200, 20)
+        also["m3_array_materials"] = measure_single("m3", 100, 10, "arrays")
+        also["m2"] = measure_single("m2", 1000, 20)
+        also["m3v64"] = measure_single("m3v64", 100, 10)
+        out["also"] = also
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
+            out["cpu_baseline"] = cpu_baseline(workload)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -53,7 +53,8 @@ struct BulkArgs {
   T* F;
   const T* G;
   const T* mat;
-  const T* ghost;  // neighbour slab's plane of G (ny,nz,3) or null at a true domain edge
+  const T* ghost;  // x-slabs: the two components of G that cross an x face (y, z), taken from
+                   // the neighbour slab's adjacent plane, (ny,nz,2); null at a true domain edge
   int nx, ny, nz;
   int x0, x1;      // planes to process
   T sc;            // Courant number

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void bulk_E_generic(BulkArgs<T> a) {
   if (j > 0) { d.y_z = hz - G[c3 - sy + 2]; d.y_x = hx - G[c3 - sy]; }
   if (k > 0) { d.z_y = hy - G[c3 - sz + 1]; d.z_x = hx - G[c3 - sz]; }
   if (i > 0) { d.x_z = hz - G[c3 - sx + 2]; d.x_y = hy - G[c3 - sx + 1]; }
-  else if (a.ghost) { d.x_z = hz - a.ghost[r * 3 + 2]; d.x_y = hy - a.ghost[r * 3 + 1]; }
+  else if (a.ghost) { d.x_z = hz - a.ghost[r * 2 + 1]; d.x_y = hy - a.ghost[r * 2]; }
 
   T e[3] = {a.F[c3], a.F[c3 + 1], a.F[c3 + 2]};
   T m[3];
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void bulk_H_generic(BulkArgs<T> a) {
   if (j < a.ny - 1) { d.y_z = G[c3 + sy + 2] - ez; d.y_x = G[c3 + sy] - ex; }
   if (k < a.nz - 1) { d.z_y = G[c3 + sz + 1] - ey; d.z_x = G[c3 + sz] - ex; }
   if (i < a.nx - 1) { d.x_z = G[c3 + sx + 2] - ez; d.x_y = G[c3 + sx + 1] - ey; }
-  else if (a.ghost) { d.x_z = a.ghost[r * 3 + 2] - ez; d.x_y = a.ghost[r * 3 + 1] - ey; }
+  else if (a.ghost) { d.x_z = a.ghost[r * 2 + 1] - ez; d.x_y = a.ghost[r * 2] - ey; }
 
   T h[3] = {a.F[c3], a.F[c3 + 1], a.F[c3 + 2]};
   T m[3];

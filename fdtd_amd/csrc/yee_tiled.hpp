@@ -120,8 +120,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
   const int64_t c3 = (int64_t)i * sx + r3;
   const T* __restrict__ g = a.G + c3;
 
-  const bool hasx = i > 0 || a.ghost != nullptr, hasy = j > 0, hasz = k > 0;
-  const T* gx = i > 0 ? g - sx : (a.ghost ? a.ghost + r3 : g);
+  // plane 0 of an x-slab takes the x neighbour's two components from the ghost plane
+  // (wave-uniform: the plane index is the same for the whole workgroup)
+  const bool from_ghost = i == 0 && a.ghost != nullptr;
+  const bool hasx = i > 0 || from_ghost, hasy = j > 0, hasz = k > 0;
+  const T* gx = i > 0 ? g - sx : g;
   const T* gy = hasy ? g - sy : g;
   const T* gz = hasz ? g - 3 : g;
 
@@ -134,6 +137,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
   T e[3], m[3];
   load3<T, NT>(a.F + c3, e[0], e[1], e[2]);
   cell_material<T, NT, HAS_OBJ>(a, c3, i, j, k, m);
+  if (from_ghost) {
+    const T* gh = a.ghost + ((int64_t)j * a.nz + k) * 2;
+    xy = gh[0]; xz = gh[1];
+  }
   (void)xx; (void)yy; (void)zz_;
 
   Diffs<T> d;
@@ -157,8 +164,9 @@ __global__ __launch_bounds__(256) void bulk_H_rows(BulkArgs<T> a) {
   const int64_t c3 = (int64_t)i * sx + r3;
   const T* __restrict__ g = a.G + c3;
 
-  const bool hasx = i < a.nx - 1 || a.ghost != nullptr, hasy = j < a.ny - 1, hasz = k < a.nz - 1;
-  const T* gx = i < a.nx - 1 ? g + sx : (a.ghost ? a.ghost + r3 : g);
+  const bool from_ghost = i == a.nx - 1 && a.ghost != nullptr;   // last plane of an x-slab
+  const bool hasx = i < a.nx - 1 || from_ghost, hasy = j < a.ny - 1, hasz = k < a.nz - 1;
+  const T* gx = i < a.nx - 1 ? g + sx : g;
   const T* gy = hasy ? g + sy : g;
   const T* gz = hasz ? g + 3 : g;
 
@@ -171,6 +179,10 @@ __global__ __launch_bounds__(256) void bulk_H_rows(BulkArgs<T> a) {
   T h[3], m[3];
   load3<T, NT>(a.F + c3, h[0], h[1], h[2]);
   cell_material<T, NT, false>(a, c3, i, j, k, m);
+  if (from_ghost) {
+    const T* gh = a.ghost + ((int64_t)j * a.nz + k) * 2;
+    xy = gh[0]; xz = gh[1];
+  }
   (void)xx; (void)yy; (void)zz_;
 
   Diffs<T> d;

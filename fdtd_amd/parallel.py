@@ -4,14 +4,15 @@ The reference is single device (no counterpart).  What decomposes: along x,
 ``update_E`` at plane i needs Hy, Hz of plane i-1 (reference fdtd/grid.py:71,73) and
 ``update_H`` at plane i needs Ey, Ez of plane i+1 (fdtd/grid.py:46,48); nothing else
 crosses an x face.  So every rank owns a contiguous range of x planes of all four
-field arrays and, per half step, receives ONE plane from one neighbour:
+field arrays and, per half step, receives the two tangential components of ONE plane
+from one neighbour (``Ny * Nz * 2`` values):
 
-    before update_E : last H plane of rank r-1  ->  ``H_below`` of rank r
-    before update_H : first E plane of rank r+1 ->  ``E_above`` of rank r
+    before update_E : (Hy, Hz) of the last plane of rank r-1  ->  ``H_below`` of rank r
+    before update_H : (Ey, Ez) of the first plane of rank r+1 ->  ``E_above`` of rank r
 
-A plane of the ``(Nx, Ny, Nz, 3)`` layout is one contiguous block, so planes are sent
-straight out of the field arrays and received into two small ghost buffers that
-the kernels read in place of the domain-edge mask (``fdtdhip_plan_set_halo``).
+The sender packs the two components into a contiguous ``(Ny, Nz, 2)`` buffer (one small
+copy), the receiver's ghost buffer has the same shape and the kernels read it in place of
+the domain-edge mask (``fdtdhip_plan_set_halo``).
 
 Overlap: the exchange is started first, the interior planes (which do not need the
 ghost) are enqueued on the compute stream, then the stream waits for the exchange
@@ -112,10 +113,12 @@ class SlabGrid(Grid):
         self._world = dist.get_world_size(group)
         self._backend_name = dist.get_backend(group)
         super().__init__(shape, grid_spacing, permittivity, permeability, courant_number)
-        plane = (self.Ny, self.Nz, 3)
+        plane = (self.Ny, self.Nz, 2)     # the two components tangential to an x face
         self._H_below = bd.zeros(plane) if self._rank > 0 else None
         self._E_above = bd.zeros(plane) if self._rank < self._world - 1 else None
         self._halo = (self._H_below, self._E_above)
+        self._send_H = bd.zeros(plane) if self._rank < self._world - 1 else None
+        self._send_E = bd.zeros(plane) if self._rank > 0 else None
         self._engine = (engine_factory or _NativeEngine)(self)
 
     # ------------------------------------------------------------ decomposition
@@ -191,11 +194,19 @@ class SlabGrid(Grid):
             ops.append(dist.P2POp(dist.irecv, recv, self._global_rank(src), self._group))
         return _Exchange(dist.batch_isend_irecv(ops), staged)
 
+    @staticmethod
+    def _tangential(plane, buf):
+        """Components y and z of an x plane, packed into the send buffer."""
+        if buf.dtype != plane.dtype or buf.device != plane.device:
+            buf = torch.empty(plane.shape[:-1] + (2,), dtype=plane.dtype, device=plane.device)
+        buf.copy_(plane.detach()[..., 1:])
+        return buf
+
     # ----------------------------------------------------------------- stepping
     def _half_step_E(self, eng, q):
         r, p = self._rank, self._world
-        ex = self._start_exchange(self.H[-1] if r < p - 1 else None, r + 1,
-                                  self._H_below, r - 1)
+        ex = self._start_exchange(self._tangential(self.H[-1], self._send_H) if r < p - 1 else None,
+                                  r + 1, self._H_below, r - 1)
         first = 1 if r > 0 else 0
         eng.bulk_E(first, self.Nx)       # planes that do not need the ghost plane
         if ex is not None:
@@ -221,8 +232,8 @@ class SlabGrid(Grid):
             if getattr(self, "_H_ring", None) is None:
                 self._H_ring = bd.zeros((self.Ny, self.Nz, 3))
             eng.defer_currents(self._H_ring)   # before the post pieces: they leave these out
-        ex = self._start_exchange(self.E[0] if r > 0 else None, r - 1,
-                                  self._E_above, r + 1)
+        ex = self._start_exchange(self._tangential(self.E[0], self._send_E) if r > 0 else None,
+                                  r - 1, self._E_above, r + 1)
         last = self.Nx - 1 if r < p - 1 else self.Nx
         eng.bulk_H(0, last)
         if ex is not None:

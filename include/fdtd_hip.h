@@ -87,11 +87,12 @@ int fdtdhip_plan_set_fields(fdtdhip_plan* plan, void* E, void* H,
                             const void* inv_permittivity, const void* inv_permeability);
 
 /* x-slab decomposition (no reference counterpart: the reference is single
- * device).  `H_below`: (ny,nz,3) copy of the neighbour's last H plane, used by
- * update_E for plane 0 instead of the domain-edge mask of reference
- * fdtd/grid.py:71,73.  `E_above`: the neighbour's first E plane, used by
- * update_H for the last plane instead of the mask of fdtd/grid.py:46,48.
- * NULL = true domain edge. */
+ * device).  Only two components cross an x face: update_E at plane i reads Hy, Hz
+ * of plane i-1 (reference fdtd/grid.py:71,73), update_H at plane i reads Ey, Ez of
+ * plane i+1 (fdtd/grid.py:46,48).  `H_below`: device (ny,nz,2) array holding (Hy, Hz)
+ * of the neighbour's last plane, used by update_E for plane 0 instead of the
+ * domain-edge mask.  `E_above`: (Ey, Ez) of the neighbour's first plane, used by
+ * update_H for the last plane.  NULL = true domain edge. */
 int fdtdhip_plan_set_halo(fdtdhip_plan* plan, const void* H_below, const void* E_above);
 
 /* PML slab (reference fdtd/boundaries.py:356-476).  axis 0..2, side 0 = low /

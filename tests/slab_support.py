@@ -43,6 +43,15 @@ class _SlabDirectionalPoint:
         pass
 
 
+def _plane3(ghost):
+    """A slab's ghost buffer -- (Ny, Nz, 2): the y and z components of the neighbour's
+    plane -- as the three-component plane the oracle's curls take (x component unused)."""
+    if ghost is None:
+        return None
+    h = ghost.numpy()
+    return np.concatenate([np.zeros(h.shape[:-1] + (1,), h.dtype), h], axis=-1)
+
+
 class OracleSlabEngine:
     def __init__(self, grid):
         self.grid = grid
@@ -183,14 +192,14 @@ class OracleSlabEngine:
         self._check_cover("E")
         g, og = self.grid, self.og
         og.time_steps_passed = q
-        og.halo_lo_H = g._H_below.numpy() if g._H_below is not None else None
+        og.halo_lo_H = _plane3(g._H_below)
         og.update_E()
 
     def post_H(self, q):
         self._check_cover("H")
         g, og = self.grid, self.og
         og.time_steps_passed = q
-        og.halo_hi_E = g._E_above.numpy() if g._E_above is not None else None
+        og.halo_hi_E = _plane3(g._E_above)
         if getattr(self, "below", None) is None:
             og.update_H()
         else:   # the statements of OracleGrid.update_H with the current detectors left out
@@ -208,7 +217,7 @@ class OracleSlabEngine:
             og.time_steps_passed = q
             for b in og.boundaries:
                 b.update_phi_E()
-            curl = orc.curl_H(og.H, g._H_below.numpy() if g._H_below is not None else None)
+            curl = orc.curl_H(og.H, _plane3(g._H_below))
             og.E += og.courant_number * og.inverse_permittivity * curl
             for o in og.objects:
                 o.update_E(curl)
@@ -229,7 +238,7 @@ class OracleSlabEngine:
             og.time_steps_passed = q
             for b in og.boundaries:
                 b.update_phi_H()
-            curl = orc.curl_E(og.E, g._E_above.numpy() if g._E_above is not None else None)
+            curl = orc.curl_E(og.E, _plane3(g._E_above))
             og.H -= og.courant_number * og.inverse_permeability * curl
             for b in og.boundaries[:k]:
                 b.update_H()
