@@ -56,32 +56,70 @@ __device__ __forceinline__ void store3_wave(double* cell_ptr, double x, double y
     store3<double, NTS>(cell_ptr, x, y, z);
     return;
   }
-  volatile double* l = lds_wave;
+  double* l = lds_wave;
   l[lane * 3] = x; l[lane * 3 + 1] = y; l[lane * 3 + 2] = z;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   double* out = cell_ptr - lane * 3;   // the wave's first cell
-  const double a0 = l[lane * 2], a1 = l[lane * 2 + 1];
+  const double a0 = l[lane], a1 = l[64 + lane], a2 = l[128 + lane];
   if (NTS) {
-    __builtin_nontemporal_store(a0, out + lane * 2);
-    __builtin_nontemporal_store(a1, out + lane * 2 + 1);
+    __builtin_nontemporal_store(a0, out + lane);
+    __builtin_nontemporal_store(a1, out + 64 + lane);
+    __builtin_nontemporal_store(a2, out + 128 + lane);
   } else {
-    out[lane * 2] = a0; out[lane * 2 + 1] = a1;
-  }
-  if (lane < 32) {
-    const double b0 = l[128 + lane * 2], b1 = l[128 + lane * 2 + 1];
-    if (NTS) {
-      __builtin_nontemporal_store(b0, out + 128 + lane * 2);
-      __builtin_nontemporal_store(b1, out + 128 + lane * 2 + 1);
-    } else {
-      out[128 + lane * 2] = b0; out[128 + lane * 2 + 1] = b1;
-    }
+    out[lane] = a0; out[64 + lane] = a1; out[128 + lane] = a2;
   }
 }
 template <bool NTS>
 __device__ __forceinline__ void store3_wave(float* cell_ptr, float x, float y, float z, float*) {
   store3<float, NTS>(cell_ptr, x, y, z);   // 12-byte cells already store as full lines
+}
+
+// float64 loads through LDS.  A lane's 24-byte cell loads as a 16-byte and an 8-byte
+// instruction at a 24-byte lane stride: every line is touched twice, in partial pieces.
+// When the wave holds 64 consecutive cells (1536 contiguous bytes per array) the field being
+// advanced (streamed once: non-temporal) and the wave's own segment of the driving field
+// are loaded instead as dense 8-byte accesses -- lane l takes doubles l, 64+l and 128+l of
+// the segment -- and handed to their cells through LDS.  The own segment in LDS also serves
+// the z neighbour (the cell before the segment for the backward differences of the E half
+// step, the cell after it for the forward differences of the H half step, fetched by three
+// lanes); the x and y neighbours are read from memory, only the two components each
+// difference needs.  MI355X, 512^3, vacuum, constants: 1.71 against 1.87 ms per launch
+// (5.64 against 5.15 TB/s).
+constexpr int DENSE_STAGE = 200 + 192;   // doubles per wave: 3 + 192 + 3 (+2 pad), then 192
+// own[3], zn[2] (components 0, 1 of the z neighbour), f[3] of this lane's cell.
+// gcell / fcell: this lane's cell in the driving / advanced field; first / last: element
+// offsets of the arrays' first and one-past-last element relative to gcell's segment start.
+template <bool FORWARD>
+__device__ __forceinline__ void load_dense(const double* gcell, const double* fcell,
+                                           int64_t seg_elem, int64_t total_elem, double* L,
+                                           double own[3], double zn[2], double f[3]) {
+  const int lane = threadIdx.x & 63;
+  const double* gseg = gcell - 3 * lane;
+  const double* fseg = fcell - 3 * lane;
+  double* o = L + 3;
+  double* ff = L + 200;
+  const double g0 = gseg[lane], g1 = gseg[64 + lane], g2 = gseg[128 + lane];
+  const double f0 = __builtin_nontemporal_load(fseg + lane);
+  const double f1 = __builtin_nontemporal_load(fseg + 64 + lane);
+  const double f2 = __builtin_nontemporal_load(fseg + 128 + lane);
+  double edge = 0;
+  if (lane < 3) {
+    if (FORWARD) { if (seg_elem + 195 <= total_elem) edge = gseg[192 + lane]; }
+    else if (seg_elem >= 3) edge = gseg[lane - 3];
+  }
+  o[lane] = g0; o[64 + lane] = g1; o[128 + lane] = g2;
+  ff[lane] = f0; ff[64 + lane] = f1; ff[128 + lane] = f2;
+  if (lane < 3) o[FORWARD ? 192 + lane : lane - 3] = edge;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  own[0] = o[3 * lane]; own[1] = o[3 * lane + 1]; own[2] = o[3 * lane + 2];
+  const int z = FORWARD ? 3 * lane + 3 : 3 * lane - 3;
+  zn[0] = o[z]; zn[1] = o[z + 1];
+  f[0] = ff[3 * lane]; f[1] = ff[3 * lane + 1]; f[2] = ff[3 * lane + 2];
+  __builtin_amdgcn_wave_barrier();   // the store staging below reuses ff
 }
 
 // Cell of this lane.  FLAT: 256 consecutive cells of the flattened (y, z) plane per
@@ -128,14 +166,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
   const T* gy = hasy ? g - sy : g;
   const T* gz = hasz ? g - 3 : g;
 
-  T hx, hy, hz, xx, xy, xz, yx, yy, yz, zx, zy, zz_;
-  load3<T, false>(g, hx, hy, hz);
-  load3<T, false>(gx, xx, xy, xz);
-  load3<T, false>(gy, yx, yy, yz);
-  load3<T, false>(gz, zx, zy, zz_);
-  __shared__ T stage[sizeof(T) == 8 ? 4 * 192 : 1];
+  T hx = 0, hy = 0, hz = 0, xx, xy = 0, xz = 0, yx = 0, yy, yz = 0, zx = 0, zy = 0, zz_;
+  __shared__ T stage[sizeof(T) == 8 ? 4 * DENSE_STAGE : 1];
+  T* const wave_stage = stage + (sizeof(T) == 8 ? (threadIdx.x >> 6) * DENSE_STAGE : 0);
   T e[3], m[3];
-  load3<T, NT>(a.F + c3, e[0], e[1], e[2]);
+  bool dense = false;
+  if constexpr (sizeof(T) == 8) {
+    dense = __builtin_amdgcn_read_exec() == ~0ull;   // 64 consecutive cells (a prefix otherwise)
+    if (dense) {
+      // (requested before the LDS round trip of load_dense, so that all of the lane's
+      // loads are in flight together)
+      xy = gx[1]; xz = gx[2];
+      yx = gy[0]; yz = gy[2];
+      double own[3], zn[2];
+      load_dense<false>(g, a.F + c3, c3 - 3 * (threadIdx.x & 63), 3 * (int64_t)a.nx * a.ny * a.nz,
+                        wave_stage, own, zn, e);
+      hx = own[0]; hy = own[1]; hz = own[2];
+      zx = zn[0]; zy = zn[1];
+    }
+  }
+  if (!dense) {
+    load3<T, false>(g, hx, hy, hz);
+    load3<T, false>(gx, xx, xy, xz);
+    load3<T, false>(gy, yx, yy, yz);
+    load3<T, false>(gz, zx, zy, zz_);
+    load3<T, NT>(a.F + c3, e[0], e[1], e[2]);
+  }
   cell_material<T, NT, HAS_OBJ>(a, c3, i, j, k, m);
   if (from_ghost) {
     const T* gh = a.ghost + ((int64_t)j * a.nz + k) * 2;
@@ -152,7 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
   d.z_y = hasz ? hy - zy : T(0);
   const T hs[3] = {hx, hy, hz};
   finish_E<T, HAS_PML, HAS_OBJ>(a, i, j, k, d, e, m, hs);
-  store3_wave<NTS>(a.F + c3, e[0], e[1], e[2], stage + (threadIdx.x >> 6) * 192);
+  store3_wave<NTS>(a.F + c3, e[0], e[1], e[2], wave_stage + (sizeof(T) == 8 ? 200 : 0));
 }
 
 template <typename T, bool HAS_PML, bool FLAT, bool NT, bool NTS>
@@ -170,14 +226,30 @@ __global__ __launch_bounds__(256) void bulk_H_rows(BulkArgs<T> a) {
   const T* gy = hasy ? g + sy : g;
   const T* gz = hasz ? g + 3 : g;
 
-  T ex, ey, ez, xx, xy, xz, yx, yy, yz, zx, zy, zz_;
-  load3<T, false>(g, ex, ey, ez);
-  load3<T, false>(gx, xx, xy, xz);
-  load3<T, false>(gy, yx, yy, yz);
-  load3<T, false>(gz, zx, zy, zz_);
-  __shared__ T stage[sizeof(T) == 8 ? 4 * 192 : 1];
+  T ex = 0, ey = 0, ez = 0, xx, xy = 0, xz = 0, yx = 0, yy, yz = 0, zx = 0, zy = 0, zz_;
+  __shared__ T stage[sizeof(T) == 8 ? 4 * DENSE_STAGE : 1];
+  T* const wave_stage = stage + (sizeof(T) == 8 ? (threadIdx.x >> 6) * DENSE_STAGE : 0);
   T h[3], m[3];
-  load3<T, NT>(a.F + c3, h[0], h[1], h[2]);
+  bool dense = false;
+  if constexpr (sizeof(T) == 8) {
+    dense = __builtin_amdgcn_read_exec() == ~0ull;
+    if (dense) {
+      xy = gx[1]; xz = gx[2];
+      yx = gy[0]; yz = gy[2];
+      double own[3], zn[2];
+      load_dense<true>(g, a.F + c3, c3 - 3 * (threadIdx.x & 63), 3 * (int64_t)a.nx * a.ny * a.nz,
+                       wave_stage, own, zn, h);
+      ex = own[0]; ey = own[1]; ez = own[2];
+      zx = zn[0]; zy = zn[1];
+    }
+  }
+  if (!dense) {
+    load3<T, false>(g, ex, ey, ez);
+    load3<T, false>(gx, xx, xy, xz);
+    load3<T, false>(gy, yx, yy, yz);
+    load3<T, false>(gz, zx, zy, zz_);
+    load3<T, NT>(a.F + c3, h[0], h[1], h[2]);
+  }
   cell_material<T, NT, false>(a, c3, i, j, k, m);
   if (from_ghost) {
     const T* gh = a.ghost + ((int64_t)j * a.nz + k) * 2;
@@ -193,7 +265,7 @@ __global__ __launch_bounds__(256) void bulk_H_rows(BulkArgs<T> a) {
   d.z_x = hasz ? zx - ex : T(0);
   d.z_y = hasz ? zy - ey : T(0);
   finish_H<T, HAS_PML>(a, i, j, k, d, h, m);
-  store3_wave<NTS>(a.F + c3, h[0], h[1], h[2], stage + (threadIdx.x >> 6) * 192);
+  store3_wave<NTS>(a.F + c3, h[0], h[1], h[2], wave_stage + (sizeof(T) == 8 ? 200 : 0));
 }
 
 }  // namespace fdtdhip
