@@ -15,7 +15,7 @@ cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx9
 text = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.dirname(src)).stderr
 rows, cur = [], None
 for line in text.splitlines():
-    m = re.search(r"remark: +([A-Za-z ]+): +(\S+)", line)
+    m = re.search(r"remark:\s+(.+?):\s+(\S+)(?:\s+\[-R.*)?$", line)
     if not m:
         continue
     key, val = m.group(1).strip(), m.group(2)
@@ -32,6 +32,6 @@ for r, n in zip(rows, names):
     n = re.sub(r"\(fdtdhip::\w+<\w+>\)$", "", n.replace("void fdtdhip::", ""))
     if want and not all(w in n for w in want):
         continue
-    print(f"{r.get('VGPRs', '?'):>5} {r.get('AGPRs', '?'):>5} {r.get('SGPRs', '?'):>5} "
+    print(f"{r.get('VGPRs', '?'):>5} {r.get('AGPRs', '?'):>5} {r.get('TotalSGPRs', r.get('SGPRs', '?')):>5} "
           f"{r.get('ScratchSize [bytes/lane]', '?'):>8} {r.get('LDS Size [bytes/block]', '?'):>7} "
           f"{r.get('Occupancy [waves/SIMD]', '?'):>4}  {n}")
