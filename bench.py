@@ -173,32 +173,49 @@ def use_material_arrays(grid, lib, _lib):
     _lib.check(lib.fdtdhip_plan_scan_materials(grid._plan, 0))
 
 
-def roofline(grid, cells, es, ms_e, ms_h, mask, steps, workload):
-    """The dominant kernel is the bulk half-step kernel.  One half step of one GPU = `cells`
-    cells = one bulk launch on a single GPU; on a slab it is two launches (interior planes,
-    then the plane that waits for the halo), so durations are summed per half step before
-    dividing."""
+def roofline(grid, cells, es, ms_e, ms_h, mask, steps, workload, launches_e=None, launches_h=None):
+    """The dominant kernel is the bulk half-step kernel, or -- where the library takes whole
+    steps in one pass (plans without PMLs on large 3-D grids; the README example) -- the
+    whole-step kernel, whose launches the library's timer counts with the E launches.  One
+    half step of one GPU = `cells` cells = one bulk launch on a single GPU; on a slab it is
+    two launches (interior planes, then the plane that waits for the halo), so durations are
+    summed per half step before dividing.  The whole-step kernel's algorithmic bytes are both
+    fields read and written once (12 values per cell, plus the material arrays where they are
+    read).  A run of an odd number of steps ends with one step of two half-step launches; the
+    bytes of every launch are then added up and divided by the total kernel time."""
     be, bh = half_step_bytes(grid, cells, es, mask)
-    avg_ms = (ms_e + ms_h) / (2 * steps)
-    per_launch = (be + bh) / 2
+    whole = 0 if launches_e is None else max(0, launches_e - launches_h)   # whole-step launches
+    whole_bytes = be + bh - 6 * cells * es      # E and H are read once instead of twice
+    if whole:
+        halves = steps - whole                  # steps taken as two half-step launches
+        avg_ms = (ms_e + ms_h) / (whole + 2 * halves)
+        per_launch = (whole * whole_bytes + halves * (be + bh)) / (whole + 2 * halves)
+    else:
+        avg_ms = (ms_e + ms_h) / (2 * steps)
+        per_launch = (be + bh) / 2
+    whole_step = whole > 0
     achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roof = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
-        "kernel": "bulk half-step kernel (E and H)",
+        "kernel": ("one-lane-per-cell whole-step kernel" if workload == "c1"
+                   else "marching whole-step kernel (E and H in one pass)") if whole_step
+                  else "bulk half-step kernel (E and H)",
         "materials": {0: "arrays", 1: "inverse permittivity constant", 2: "inverse permeability constant",
                       3: "constants"}[mask],
         "bytes_per_launch": per_launch,
         # the same duration priced at 12 values per cell and half step whatever the
         # materials are (every array counted as read): an effective rate, not HBM traffic
-        "all_arrays_equivalent_GBps": round(cells * 12 * es / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
+        "all_arrays_equivalent_GBps": round(cells * (24 if whole_step else 12) * es / (avg_ms * 1e-3) / 1e9, 1)
+                                      if avg_ms > 0 else 0.0,
         "avg_launch_ms": round(avg_ms, 4),
-        "avg_launch_ms_E": round(ms_e / steps, 4),
+        "avg_launch_ms_E": round(ms_e / steps, 4),     # (whole-step launches are counted here)
         "avg_launch_ms_H": round(ms_h / steps, 4),
     }
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
-        rec = json.load(open(pmc)).get(f"{workload}:{roof['materials']}")
+        key = f"{workload}:{roof['materials']}" + (":whole-step" if whole_step else "")
+        rec = json.load(open(pmc)).get(key)
         if rec:
             roof["traffic"] = rec.get("bytes_per_launch")
             roof["traffic_source"] = PMC_NOTE
@@ -221,14 +238,14 @@ def measure_single(workload, steps, warmup, materials="auto"):
     torch.cuda.synchronize()
     mask = 0 if materials == "arrays" else _lib.check(lib.fdtdhip_plan_scan_materials(grid._plan, 1))
     elapsed, msE, nE, msH, nH = timed_run(grid, lib, _lib, steps, torch.cuda.synchronize)
-    roof = roofline(grid, cells, es, msE, msH, mask, steps, workload)
+    roof = roofline(grid, cells, es, msE, msH, mask, steps, workload, nE, nH)
     rec = {
         "workload": desc, "name": workload, "dtype": dt, "steps": steps, "warmup": warmup,
         "value": round(cells * steps / elapsed / 1e9, 3), "unit": "Gcells/s",
         "ms_per_step": round(elapsed / steps * 1e3, 4),
         "avg_launch_ms": roof["avg_launch_ms"], "achieved": roof["achieved"], "frac": roof["frac"],
-        "materials": roof["materials"], "bytes_per_launch": roof["bytes_per_launch"],
-        "traffic": roof["traffic"],
+        "materials": roof["materials"], "kernel": roof["kernel"],
+        "bytes_per_launch": roof["bytes_per_launch"], "traffic": roof["traffic"],
     }
     del grid
     torch.cuda.empty_cache()
@@ -412,7 +429,8 @@ def main():
     out = None
     if rank == 0:
         value = cells * world * args.steps / elapsed / 1e9
-        roof = roofline(grid, cells, es, msE, msH, mask, args.steps, workload)
+        roof = roofline(grid, cells, es, msE, msH, mask, args.steps, workload,
+                        nE if world == 1 else None, nH)
         roof["launches"] = nE + nH
         out = {
             "metric": "Yee cell-updates/s", "value": round(value, 3), "unit": "Gcells/s",

@@ -35,6 +35,7 @@ PROTOTYPES = {
     "fdtdhip_plan_set_step_buffers": (_i, [_p, _p, _p]),
     "fdtdhip_plan_set_pml_step_buffer": (_i, [_p, _i, _p]),
     "fdtdhip_plan_add_pml": (_i, [_p, _i, _i, _i, _pd, _pd, _pd, _pd, _p, _p]),
+    "fdtdhip_plan_set_pml_state": (_i, [_p, _i, _p, _p]),
     "fdtdhip_plan_add_periodic": (_i, [_p, _i]),
     "fdtdhip_plan_add_object": (_i, [_p, _i, _pi32, _p, _p]),
     "fdtdhip_plan_add_source": (_i, [_p, _i, _i, _i, _i64, _pi32, _pd, _d, _d, _i, _d, _d, _d]),

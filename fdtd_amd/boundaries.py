@@ -226,10 +226,22 @@ class PML(Boundary):
     def _signature(self):
         if not self._active:
             return ("pml-elsewhere", id(self))
+        # (the memory-variable arrays themselves are not part of it: re-bound arrays are
+        # handed to the plan by _native_refresh without rebuilding it)
         alt = getattr(self, "_psiE_alt", None)
-        return ("pml", id(self), self.axis, self.side, self.thickness,
-                self._psiE.data_ptr(), self._psiH.data_ptr(), self._psiE.dtype,
+        return ("pml", id(self), self.axis, self.side, self.thickness, tuple(self._psiE.shape),
                 alt.data_ptr() if alt is not None else 0)
+
+    def _native_refresh(self, lib, plan):
+        """Before every run: the plan follows the arrays ``_psiE`` / ``_psiH`` are bound to."""
+        if not self._active:
+            return
+        for name in ("_psiE", "_psiH"):
+            t = getattr(self, name)
+            if t.dtype != bd.float or t.device != bd.device or not t.is_contiguous():
+                setattr(self, name, t.to(device=bd.device, dtype=bd.float).contiguous())
+        _lib.check(lib.fdtdhip_plan_set_pml_state(plan, self._native_id, self._psiE.data_ptr(),
+                                                   self._psiH.data_ptr()))
 
     def _native_add(self, lib, plan):
         if not self._active:

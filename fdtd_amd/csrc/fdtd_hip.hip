@@ -21,6 +21,7 @@
 #include "yee_tiled.hpp"
 #include "yee_adjoint.hpp"
 #include "yee_step.hpp"
+#include "yee_march.hpp"
 
 namespace {
 
@@ -1072,36 +1073,51 @@ int adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH, void* w
 // without repeated cells, and the caller has provided the second buffers.
 constexpr int64_t FUSED_AUTO_MAX_CELLS = 1 << 17;
 
-bool fused_eligible(const fdtdhip_plan* p) {
-  // FDTDHIP_FUSED=0 never, =1 whenever possible.  By default only where it was measured
-  // faster than two half-step launches (MI355X, PML on every face, tools/mid_cost.py):
-  // 2-D grids up to about 420 x 420 cells (161 x 97: 9.0 against 11.4 us per step,
-  // 360^2: 12.7 / 14.1, 420^2: 15.4 / 15.7, 512^2: 17.7 / 17.1).  In 3-D the lane's four
-  // E evaluations with six faces cost more than the second launch at every size tried
-  // (32^3: 14.6 against 12.6 us, 48^3: 17.1 / 15.7, 80^3: 49 / 30), and on large grids the
-  // kernel is L1-bound (512^3 fp32: 3.2 ms against 2.2 ms).
+// Which whole-step kernel a run may use.
+//   FUSED_CELL  : step_fused, one lane per cell re-deriving its neighbours' new E -- wins on
+//                 small 2-D grids, where the launch count decides the step time;
+//   FUSED_MARCH : step_march, workgroups marching along x -- wins on large 3-D grids, where
+//                 it moves 12 instead of 18 values per cell and step.
+enum FusedKind { FUSED_NONE = 0, FUSED_CELL, FUSED_MARCH };
+
+FusedKind fused_kind(const fdtdhip_plan* p) {
+  // FDTDHIP_FUSED=0 never, =1 step_fused whenever possible, =2 step_march whenever possible
+  // (tests).  By default step_fused only where it was measured faster than two half-step
+  // launches (MI355X, PML on every face, tools/mid_cost.py): 2-D grids up to about 420 x 420
+  // cells (161 x 97: 9.0 against 11.4 us per step, 360^2: 12.7 / 14.1, 420^2: 15.4 / 15.7,
+  // 512^2: 17.7 / 17.1; in 3-D the lane's four E evaluations with six faces cost more than
+  // the second launch at every size tried, and on large grids the kernel is L1-bound), and
+  // step_march on 3-D grids without PMLs, with z rows of 128 to 1024 cells and enough rows and
+  // planes to fill the machine with workgroups (512^3 float32: 1.25 against 1.66 ms per step,
+  // 256^3: 0.187 against 0.21, 256 x 1024 x 1024: 2.67 against 3.3; float64 512^3: 3.05 / 3.34).
   static const int mode = [] {
     const char* e = getenv("FDTDHIP_FUSED");
-    return e ? (atoi(e) ? 1 : 0) : -1;
+    return e ? atoi(e) : -1;
   }();
-  if (mode == 0 || !p->E_alt || !p->H_alt) return false;
+  if (mode == 0 || !p->E_alt || !p->H_alt) return FUSED_NONE;
   for (const ObjH& o : p->objs)
-    if (o.kind == FDTDHIP_OBJ_ANISOTROPIC_MODULATED) return false;  // only the generic E kernel has them
-  if (mode < 0 && (p->cells() > FUSED_AUTO_MAX_CELLS || std::min(p->nx, std::min(p->ny, p->nz)) > 1))
-    return false;
-  if (p->H_below || p->E_above) return false;
-  if (p->nx > 65535 || (int64_t)p->ny * p->nz >= (1ll << 30)) return false;
-  if (p->cells() * 3 >= (1ll << 31)) return false;   // the kernel's element offsets are 32-bit
+    if (o.kind == FDTDHIP_OBJ_ANISOTROPIC_MODULATED) return FUSED_NONE;  // only the generic E kernel has them
+  if (p->H_below || p->E_above) return FUSED_NONE;
   for (const BoundaryRef& b : p->boundaries)
-    if (b.kind == 1) return false;
+    if (b.kind == 1) return FUSED_NONE;
   for (const PmlH& h : p->pmls)
-    if (!h.psiE_alt) return false;
+    if (!h.psiE_alt) return FUSED_NONE;
   int64_t points = 0;
   for (const SourceH& s : p->sources) {
-    if (s.kind != FDTDHIP_SRC_ADD_POINTS || s.serial) return false;
+    if (s.kind != FDTDHIP_SRC_ADD_POINTS || s.serial) return FUSED_NONE;
     points += s.n;
   }
-  return points <= MAX_STEP_SOURCES;
+  if (points > MAX_STEP_SOURCES) return FUSED_NONE;
+  const bool cell_ok = p->nx <= 65535 && (int64_t)p->ny * p->nz < (1ll << 30) &&
+                       p->cells() * 3 < (1ll << 31);   // the kernel's element offsets are 32-bit
+  const bool march_ok = p->pmls.empty() && p->nz <= 64 * MARCH_MAX_WAVES && p->nx / 16 <= 65535;
+  if (mode == 1) return cell_ok ? FUSED_CELL : FUSED_NONE;
+  if (mode == 2) return march_ok ? FUSED_MARCH : FUSED_NONE;
+  const int thin = std::min(p->nx, std::min(p->ny, p->nz));
+  if (cell_ok && p->cells() <= FUSED_AUTO_MAX_CELLS && thin == 1) return FUSED_CELL;
+  if (march_ok && p->nz >= 128 && p->ny >= 64 && p->nx >= 64 && p->cells() >= (1ll << 22))
+    return FUSED_MARCH;
+  return FUSED_NONE;
 }
 
 // Room for `n` more readings of every detector, checked before a fused pair of steps
@@ -1146,14 +1162,48 @@ int build_detmap(fdtdhip_plan* p) {
   return 0;
 }
 
+// The marching step (yee_march.hpp): 4 rows per workgroup in float32, 2 in float64 (about 100
+// registers, 4 waves per SIMD).  Plans with PMLs do not take it: with the face code evaluated
+// row after row every workgroup waits, plane by plane, for its two waves on the z faces to
+// walk their chain of memory-variable round trips (512^3 float32, six faces: 4.6 ms per step
+// with 2 rows, 6.2 ms with 3, against 1.81 ms for two half-step launches).
 template <typename T>
-int fused_step(fdtdhip_plan* p, int64_t q) {
+int launch_march(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
+  constexpr int TY = sizeof(T) == 4 ? 4 : 2;
+  MarchArgs<T> m;
+  m.s = a;
+  const int tiles = (p->ny + TY - 1) / TY;
+  // chunks of planes short enough for about four workgroups per CU, 16 planes at least
+  int lx = (int)std::min<int64_t>(128, std::max<int64_t>(16, (int64_t)p->nx * tiles / 1024));
+  static const int forced_lx = [] {
+    const char* e = getenv("FDTDHIP_MARCH_LX");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced_lx > 0) lx = forced_lx;
+  m.lx = lx;
+  const int waves = (p->nz + 63) / 64;
+  const dim3 grid(tiles, (p->nx + lx - 1) / lx, 1), block(64 * waves);
+  const bool constants = p->mat_const[0] && p->mat_const[1];
+  // (a kernel limited to 8 waves per workgroup may use 256 registers, one for z rows of up to
+  // 1024 cells 128)
+#define MARCH(MW)                                                                                     \
+  if (obj) hipLaunchKernelGGL((step_march<T, TY, false, true, false, MW>), grid, block, 0, p->stream, m); \
+  else if (constants) hipLaunchKernelGGL((step_march<T, TY, false, false, true, MW>), grid, block, 0, p->stream, m); \
+  else hipLaunchKernelGGL((step_march<T, TY, false, false, false, MW>), grid, block, 0, p->stream, m);
+  if (waves <= 8) { MARCH(8) } else { MARCH(MARCH_MAX_WAVES) }
+#undef MARCH
+  return 0;
+}
+
+template <typename T>
+int fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {
   if (int rc = sync_obj_table<T>(p)) return rc;
-  if (p->detmap_state == 0)
+  const bool march = kind == FUSED_MARCH;   // reads no detectors itself
+  if (!march && p->detmap_state == 0)
     if (int rc = build_detmap(p)) return rc;
   StepArgs<T> a;
   a.detmap = nullptr;
-  if (p->detmap_state == 1) {
+  if (!march && p->detmap_state == 1) {
     int slot = 0;
     for (DetH& d : p->dets) {
       if (d.kind != FDTDHIP_DET_CELLS || d.n == 0) continue;
@@ -1215,7 +1265,9 @@ int fused_step(fdtdhip_plan* p, int64_t q) {
     }
     HIPCHK(hipEventRecord(p->ev_pool[slot].first, p->stream));
   }
-  if (pml && obj) hipLaunchKernelGGL((step_fused<T, true, true>), grid, block, 0, p->stream, a);
+  if (march) {
+    if (int rc = launch_march<T>(p, a, obj)) return rc;
+  } else if (pml && obj) hipLaunchKernelGGL((step_fused<T, true, true>), grid, block, 0, p->stream, a);
   else if (pml) hipLaunchKernelGGL((step_fused<T, true, false>), grid, block, 0, p->stream, a);
   else if (obj) hipLaunchKernelGGL((step_fused<T, false, true>), grid, block, 0, p->stream, a);
   else hipLaunchKernelGGL((step_fused<T, false, false>), grid, block, 0, p->stream, a);
@@ -1464,6 +1516,19 @@ int fdtdhip_plan_add_pml(fdtdhip_plan* p, int axis, int side, int t, const doubl
   p->pml_dirty = true;
   p->boundaries.push_back({0, (int)p->pmls.size() - 1});
   return (int)p->pmls.size() - 1;
+}
+
+int fdtdhip_plan_set_pml_state(fdtdhip_plan* p, int id, void* psiE, void* psiH) {
+  if (!p) return fail(-1, "null plan");
+  if (id < 0 || id >= (int)p->pmls.size()) return fail(-1, "unknown PML id");
+  if (!psiE || !psiH) return fail(-1, "null PML array");
+  PmlH& h = p->pmls[id];
+  if (h.psiE == psiE && h.psiH == psiH) return 0;
+  if (p->step_flipped) return fail(-1, "internal: PML state re-bound between the steps of a fused pair");
+  h.psiE = psiE;
+  h.psiH = psiH;
+  p->pml_dirty = true;
+  return 0;
 }
 
 int fdtdhip_plan_add_periodic(fdtdhip_plan* p, int axis) {
@@ -1744,7 +1809,7 @@ int fdtdhip_update_H(fdtdhip_plan* p, int64_t q) {
 int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
   if (!p) return fail(-1, "null plan");
   int64_t s = 0;
-  if (fused_eligible(p)) {
+  if (const FusedKind kind = fused_kind(p)) {
     // pairs of fused steps: first -> second buffers and back, so that the state ends
     // where the caller's tensors are; an odd last step runs as two half steps
     GUARD(p);
@@ -1752,7 +1817,8 @@ int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
     for (; s + 1 < nsteps; s += 2) {
       if (int rc = capacity_check(p, 2)) return rc;
       for (int k = 0; k < 2; ++k) {
-        const int rc = DISPATCH(p, fused_step<float>(p, q0 + s + k), fused_step<double>(p, q0 + s + k));
+        const int rc = DISPATCH(p, fused_step<float>(p, q0 + s + k, kind),
+                                fused_step<double>(p, q0 + s + k, kind));
         if (rc) {
           // the state of the fields now sits in the second buffers (or between the two sets)
           if (p->step_flipped) p->poisoned = true;

@@ -1,0 +1,198 @@
+// Whole Yee step in one pass for large 3-D grids: a workgroup marches along x.
+//
+// Two half-step passes move 18 values per cell and step through HBM even with constant
+// materials (each pass reads both fields and writes one).  Here a step reads E and H once
+// and writes the new E and H once: 12 values.  Out of place (E0, H0 -> E1, H1), like the
+// one-lane-per-cell step_fused of yee_step.hpp, but without its thirteen neighbour loads
+// per lane:
+//
+//   * a workgroup owns TY consecutive rows (y) of whole z rows and walks a chunk of x
+//     planes; wave w of the workgroup holds the z segment [64 w, 64 w + 64), so every load
+//     of a wave is a contiguous row segment, as in the half-step row kernels;
+//   * a lane keeps, for each of its rows, H and the new E of the previous plane in
+//     registers.  The new E of plane i needs H of plane i (own cell, the row above -- the
+//     lane's own previous row or one extra row loaded above the tile -- and the cell
+//     before, re-read through L1) and H of plane i-1 (registers).  The new H of plane i-1
+//     needs the new E of plane i-1 at the cell (registers), at the row below (the lane's
+//     next row: the row below the last owned one is evaluated redundantly, E only), at the
+//     cell after (the next lane's register by a lane shift; for a wave's last lane the
+//     first lane of the next wave, handed over through LDS with one workgroup barrier per
+//     plane) and of plane i (just computed);
+//   * chunks of the x range start one plane early for H of the plane before (read) and
+//     evaluate the new E of one plane past their end redundantly.
+//
+// Redundant evaluations use the same operations on the same operands as the owner's, so
+// the result equals two half steps bit for bit; only owners store fields, PML memory
+// variables (psi_E into the second buffer: neighbours still read the old one) and curl
+// traces.  Per cell and step: (TY+2)/TY rows of H and (TY+1)/TY rows of E read, one row of
+// each written, times (LX+1)/LX for the reads.
+//
+// MI355X, 512^3 float32 vacuum, constants: 1.17 ms per step against 1.66 ms for two
+// half-step launches (TY = 4: 97 registers, 4 waves per SIMD; TY = 2: 1.26 ms, 3: 1.23,
+// 5: 1.32, 8: 1.40; chunks of 16 to 128 planes within 2 %, a single chunk 2.6 ms).
+#pragma once
+
+#include "plan.hpp"
+#include "yee_generic.hpp"
+#include "yee_step.hpp"
+
+namespace fdtdhip {
+
+constexpr int MARCH_MAX_WAVES = 16;   // z rows of up to 1024 cells
+
+template <typename T>
+struct MarchArgs {
+  StepArgs<T> s;
+  int lx;          // planes per chunk
+};
+
+// Additive point sources on the new E of one cell (reference fdtd/grid.py:293-295).
+template <typename T>
+__device__ __forceinline__ void march_sources(const StepArgs<T>& a, int64_t c3, T e[3]) {
+#pragma unroll
+  for (int n = 0; n < MAX_STEP_SOURCES; ++n) {
+    if (n >= a.nsrc) break;
+    const int64_t off = a.src_elem[n] - c3;
+    const T v = a.src_value[n];
+    if (__any(off >= 0 && off < 3)) {
+#pragma unroll
+      for (int x = 0; x < 3; ++x) e[x] = off == x ? e[x] + v : e[x];
+    }
+  }
+}
+
+// CONST: both material arrays were proven constant (no branch on it per cell).
+template <typename T, int TY, bool HAS_PML, bool HAS_OBJ, bool CONST, int MW = MARCH_MAX_WAVES>
+__global__ __launch_bounds__(64 * MW) void step_march(MarchArgs<T> ma) {
+  const StepArgs<T>& a = ma.s;
+  const BulkArgs<T>& A = a.e;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int k = w * 64 + lane;
+  const int nx = A.nx, ny = A.ny, nz = A.nz;
+  const bool kin = k < nz;
+  const int j0 = blockIdx.x * TY;
+  const int i0 = blockIdx.y * ma.lx, i1 = min(i0 + ma.lx, nx);
+  const int64_t sy = 3 * (int64_t)nz, sx = sy * ny;
+  const T* __restrict__ H0 = A.G;
+  const T* __restrict__ E0 = A.F;
+  // new E (components x, y) of each wave's first lane, for the last lane of the wave before
+  __shared__ T xch[2][MARCH_MAX_WAVES + 1][TY][2];
+  T Hp[TY + 1][3], Ep[TY + 1][3];
+#pragma unroll
+  for (int r = 0; r <= TY; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { Hp[r][c] = T(0); Ep[r][c] = T(0); }
+  if (i0 > 0 && kin) {
+#pragma unroll
+    for (int r = 0; r <= TY; ++r) {
+      const int j = j0 + r;
+      if (j < ny) {
+        const T* p = H0 + (int64_t)(i0 - 1) * sx + (int64_t)j * sy + 3 * k;
+        Hp[r][0] = p[0]; Hp[r][1] = p[1]; Hp[r][2] = p[2];
+      }
+    }
+  }
+  const bool hasz = k > 0, hasz1 = k < nz - 1;
+  for (int i = i0; i <= i1; ++i) {
+    T Hc[TY + 1][3], En[TY + 1][3];
+#pragma unroll
+    for (int r = 0; r <= TY; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { Hc[r][c] = T(0); En[r][c] = T(0); }
+    const bool plane = i < nx;
+    if (plane && kin) {
+      const int64_t pbase = (int64_t)i * sx + 3 * k;
+      // every load of the plane is requested before the first one is used
+      T zx[TY + 1], zy[TY + 1], ux = T(0), uz = T(0);
+#pragma unroll
+      for (int r = 0; r <= TY; ++r) {
+        const int j = j0 + r;
+        zx[r] = zy[r] = T(0);
+        if (j < ny) {
+          const int64_t c3 = pbase + (int64_t)j * sy;
+          Hc[r][0] = H0[c3]; Hc[r][1] = H0[c3 + 1]; Hc[r][2] = H0[c3 + 2];
+          En[r][0] = __builtin_nontemporal_load(E0 + c3);
+          En[r][1] = __builtin_nontemporal_load(E0 + c3 + 1);
+          En[r][2] = __builtin_nontemporal_load(E0 + c3 + 2);
+          const T* z = H0 + (hasz ? c3 - 3 : c3);
+          zx[r] = z[0]; zy[r] = z[1];
+        }
+      }
+      if (j0 > 0) {
+        const T* u = H0 + pbase + (int64_t)(j0 - 1) * sy;
+        ux = u[0]; uz = u[2];
+      }
+      const bool hasx = i > 0;
+#pragma unroll
+      for (int r = 0; r <= TY; ++r) {
+        const int j = j0 + r;
+        if (j >= ny) continue;
+        const int64_t c3 = pbase + (int64_t)j * sy;
+        const bool hasy = j > 0;
+        const T yx = r == 0 ? ux : Hc[r == 0 ? 0 : r - 1][0];
+        const T yz = r == 0 ? uz : Hc[r == 0 ? 0 : r - 1][2];
+        Diffs<T> d;
+        d.x_y = hasx ? Hc[r][1] - Hp[r][1] : T(0);
+        d.x_z = hasx ? Hc[r][2] - Hp[r][2] : T(0);
+        d.y_x = hasy ? Hc[r][0] - yx : T(0);
+        d.y_z = hasy ? Hc[r][2] - yz : T(0);
+        d.z_x = hasz ? Hc[r][0] - zx[r] : T(0);
+        d.z_y = hasz ? Hc[r][1] - zy[r] : T(0);
+        const bool owner = r < TY && i < i1;
+        T m[3];
+        if (CONST && !HAS_OBJ) { m[0] = A.bg[0]; m[1] = A.bg[1]; m[2] = A.bg[2]; }
+        else cell_material<T, false, HAS_OBJ>(A, c3, i, j, k, m);
+        finish_E<T, HAS_PML, HAS_OBJ>(A, i, j, k, d, En[r], m, Hc[r], owner);
+        if (a.nsrc > 0) march_sources<T>(a, c3, En[r]);
+        if (owner) {
+          T* o = a.E1 + c3;
+          __builtin_nontemporal_store(En[r][0], o);
+          __builtin_nontemporal_store(En[r][1], o + 1);
+          __builtin_nontemporal_store(En[r][2], o + 2);
+        }
+      }
+    }
+    if (i > i0) {
+      // new H of plane i-1, owned rows
+      const int ih = i - 1;
+#pragma unroll
+      for (int r = 0; r < TY; ++r) {
+        const int j = j0 + r;
+        // new E of the cell after this one: the next lane's, or the next wave's first lane
+        T ax = __shfl_down(Ep[r][0], 1), ay = __shfl_down(Ep[r][1], 1);
+        if (lane == 63) { ax = xch[(i - 1) & 1][w + 1][r][0]; ay = xch[(i - 1) & 1][w + 1][r][1]; }
+        if (kin && j < ny) {
+          const bool hasy1 = j < ny - 1;
+          Diffs<T> d;
+          d.x_y = plane ? En[r][1] - Ep[r][1] : T(0);
+          d.x_z = plane ? En[r][2] - Ep[r][2] : T(0);
+          d.y_x = hasy1 ? Ep[r + 1][0] - Ep[r][0] : T(0);
+          d.y_z = hasy1 ? Ep[r + 1][2] - Ep[r][2] : T(0);
+          d.z_x = hasz1 ? ax - Ep[r][0] : T(0);
+          d.z_y = hasz1 ? ay - Ep[r][1] : T(0);
+          const int64_t c3 = (int64_t)ih * sx + (int64_t)j * sy + 3 * k;
+          T h[3] = {Hp[r][0], Hp[r][1], Hp[r][2]};
+          T m[3];
+          if (CONST) { m[0] = a.h.bg[0]; m[1] = a.h.bg[1]; m[2] = a.h.bg[2]; }
+          else cell_material<T, false, false>(a.h, c3, ih, j, k, m);
+          finish_H<T, HAS_PML>(a.h, ih, j, k, d, h, m);
+          T* o = a.H1 + c3;
+          __builtin_nontemporal_store(h[0], o);
+          __builtin_nontemporal_store(h[1], o + 1);
+          __builtin_nontemporal_store(h[2], o + 2);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r <= TY; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { Hp[r][c] = Hc[r][c]; Ep[r][c] = En[r][c]; }
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < TY; ++r) { xch[i & 1][w][r][0] = En[r][0]; xch[i & 1][w][r][1] = En[r][1]; }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace fdtdhip

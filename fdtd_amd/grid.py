@@ -298,10 +298,11 @@ class Grid:
         _lib.check(lib.fdtdhip_plan_set_fields(
             self._plan, E.data_ptr(), H.data_ptr(), ie.data_ptr(), im.data_ptr()))
         self._scan_materials(lib, ie, im)
-        for o in self.objects:
-            refresh = getattr(o, "_native_refresh", None)
-            if refresh is not None:
-                refresh(lib, self._plan)
+        for group in (self.objects, self.boundaries):
+            for o in group:
+                refresh = getattr(o, "_native_refresh", None)
+                if refresh is not None:
+                    refresh(lib, self._plan)
         alt = getattr(self, "_step_buffers", None)
         if alt is not None and (alt[0].shape != E.shape or alt[0].dtype != E.dtype
                                 or alt[0].device != E.device):

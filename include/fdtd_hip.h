@@ -108,6 +108,13 @@ int fdtdhip_plan_add_pml(fdtdhip_plan* plan, int axis, int side, int thickness,
                          const double* bE, const double* cE, const double* bH,
                          const double* cH, void* psiE, void* psiH);
 
+/* Point PML `id` at other memory-variable arrays of the same shape (a caller that keeps
+ * the state of a run in fresh arrays, as a recorded differentiable run does -- the
+ * reference's autograd likewise makes every in-place update a new tensor version,
+ * fdtd/boundaries.py:428-448).  Cheaper than rebuilding the plan: only the descriptor
+ * tables are uploaded again before the next step. */
+int fdtdhip_plan_set_pml_state(fdtdhip_plan* plan, int id, void* psiE, void* psiH);
+
 /* Periodic boundary along `axis` (reference fdtd/boundaries.py:173-208); axis may be
  * FDTDHIP_PERIODIC_X_EXTERNAL (see fdtdhip_update_E_post_stage).  Along an axis of one
  * cell the copy maps a plane onto itself (boundaries.py:177, 182 with index 0 == -1); it

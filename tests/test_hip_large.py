@@ -246,11 +246,13 @@ def test_large_grid_kernels_on_small_ragged_shapes():
     assert " passed" in done.stdout
 
 
-@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("fused", ["1", "2", "0"])
 def test_one_launch_step_forced_on_and_off(fused):
-    """By default the library takes the one-launch step for small 2-D grids only.
-    FDTDHIP_FUSED=1 applies it wherever the plan allows (3-D scenes too), FDTDHIP_FUSED=0
-    nowhere: every golden scene must match the reference either way, and so must the
+    """By default the library takes a one-launch step for small 2-D grids (one lane per
+    cell) and for large 3-D grids (workgroups marching along x) only.  FDTDHIP_FUSED=1
+    applies the former wherever the plan allows (3-D scenes too), FDTDHIP_FUSED=2 the latter
+    (2-D, 1-D and ragged scenes too), FDTDHIP_FUSED=0
+    neither: every golden scene must match the reference either way, and so must the
     differentiable runs (the one-launch step records their curl traces; the paired adjoint
     launches follow the same switch).  Read once per process, hence the child process."""
     import os
