@@ -85,7 +85,7 @@ class _Run(torch.autograd.Function):
         plan = grid._plan
         traces, etraces = [], []
         for o in objs:
-            tr = bd.zeros((n, o.Nx * o.Ny * o.Nz, 3))
+            tr = torch.empty((n, o.Nx * o.Ny * o.Nz, 3), dtype=bd.float, device=bd.device)   # every row is written
             _lib.check(lib.fdtdhip_plan_set_object_trace(plan, o._native_id, _ptr(tr), n))
             traces.append(tr)
         for o in mods:

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <set>
 #include <string>
@@ -137,7 +138,20 @@ struct DetH {
 
 }  // namespace
 
+// Pinned host staging for the small descriptor tables: a table is copied to the device with a
+// stream-ordered copy out of one of a few pinned buffers, so that the host does not have to
+// wait for the stream (a differentiable training loop re-points traces and state arrays for
+// every recorded step).  A buffer is reused only after the copy out of it has completed.
+struct StagingRing {
+  static constexpr int SLOTS = 8;
+  void* host[SLOTS] = {};
+  size_t cap[SLOTS] = {};
+  hipEvent_t done[SLOTS] = {};
+  int next = 0;
+};
+
 struct fdtdhip_plan {
+  StagingRing staging;
   int nx, ny, nz, dtype, device;
   double sc;
   hipStream_t stream = nullptr;
@@ -227,6 +241,35 @@ int upload_profile(fdtdhip_plan* p, const double* host, int n, void** out) {
   return 0;
 }
 
+// Stream-ordered copy of `bytes` at `src` (host) to `dst` (device).  Without waiting for the
+// stream, except inside the no-allocation entry point, which may not create the pinned
+// buffers and copies out of the caller's memory instead.
+int upload_table(fdtdhip_plan* p, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  if (p->no_alloc) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return 0;
+  }
+  StagingRing& r = p->staging;
+  const int slot = r.next;
+  r.next = (r.next + 1) % StagingRing::SLOTS;
+  if (r.done[slot]) HIPCHK(hipEventSynchronize(r.done[slot]));
+  else HIPCHK(hipEventCreateWithFlags(&r.done[slot], hipEventDisableTiming));
+  if (r.cap[slot] < bytes) {
+    if (r.host[slot]) HIPCHK(hipHostFree(r.host[slot]));
+    r.host[slot] = nullptr;
+    r.cap[slot] = 0;
+    const size_t want = std::max<size_t>(bytes, 4096);
+    HIPCHK(hipHostMalloc(&r.host[slot], want, hipHostMallocDefault));
+    r.cap[slot] = want;
+  }
+  memcpy(r.host[slot], src, bytes);
+  HIPCHK(hipMemcpyAsync(dst, r.host[slot], bytes, hipMemcpyHostToDevice, p->stream));
+  HIPCHK(hipEventRecord(r.done[slot], p->stream));
+  return 0;
+}
+
 template <typename T>
 int sync_obj_table(fdtdhip_plan* p) {
   if (!p->obj_dirty) return 0;
@@ -259,9 +302,7 @@ int sync_obj_table(fdtdhip_plan* p) {
       HIPCHK(hipMalloc(&p->obj_table, bytes));
       p->obj_table_bytes = bytes;
     }
-    // stream-ordered update, completed before the host copy goes out of scope
-    HIPCHK(hipMemcpyAsync(p->obj_table, tab.data(), bytes, hipMemcpyHostToDevice, p->stream));
-    HIPCHK(hipStreamSynchronize(p->stream));
+    if (int rc = upload_table(p, p->obj_table, tab.data(), bytes)) return rc;
   }
   p->obj_dirty = false;
   return 0;
@@ -301,8 +342,7 @@ int sync_pml_tables(fdtdhip_plan* p) {
     host[TAB_ADJ_E * MAX_PML + i] = ae;
     host[TAB_ADJ_H * MAX_PML + i] = ah;
   }
-  HIPCHK(hipMemcpyAsync(p->pml_tables, host.data(), bytes, hipMemcpyHostToDevice, p->stream));
-  HIPCHK(hipStreamSynchronize(p->stream));
+  if (int rc = upload_table(p, p->pml_tables, host.data(), bytes)) return rc;
   p->pml_dirty = false;
   return 0;
 }
@@ -1424,6 +1464,10 @@ int fdtdhip_plan_destroy(fdtdhip_plan* p) {
     release_tables(p);
     if (p->pml_tables) (void)hipFree(p->pml_tables);
     if (p->scan_flag) (void)hipFree(p->scan_flag);
+    for (int n = 0; n < StagingRing::SLOTS; ++n) {
+      if (p->staging.done[n]) (void)hipEventDestroy(p->staging.done[n]);
+      if (p->staging.host[n]) (void)hipHostFree(p->staging.host[n]);
+    }
     for (auto& e : p->ev_pool) {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);

@@ -20,10 +20,10 @@
  *     are copied into device memory owned by the plan when they are added.
  *   - A plan is not thread safe.  All work is enqueued on the plan's stream
  *     (fdtdhip_plan_set_stream).  The time-stepping calls do not wait for the
- *     device, with one exception: the first step after objects or PMLs were added
- *     or their buffers re-pointed uploads the descriptor tables and waits for that
- *     copy.  fdtdhip_plan_destroy, fdtdhip_plan_scan_materials and
- *     fdtdhip_plan_get_timing wait for the stream.
+ *     device: descriptor tables that changed (objects or PMLs added, buffers
+ *     re-pointed) are uploaded by stream-ordered copies out of pinned staging
+ *     buffers.  fdtdhip_plan_destroy, fdtdhip_plan_reset, fdtdhip_plan_scan_materials,
+ *     fdtdhip_plan_get_timing and fdtdhip_adjoint_run_noalloc wait for the stream.
  */
 #ifndef FDTD_HIP_H
 #define FDTD_HIP_H
