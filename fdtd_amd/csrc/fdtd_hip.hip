@@ -1222,7 +1222,13 @@ int launch_march(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
   if (forced_lx > 0) lx = forced_lx;
   m.lx = lx;
   const int waves = (p->nz + 63) / 64;
-  const dim3 grid(tiles, (p->nx + lx - 1) / lx, 1), block(64 * waves);
+  // tiles dealt to the XCDs in bands (see step_march); FDTDHIP_MARCH_BAND=0: plain order
+  static const bool banded = [] {
+    const char* e = getenv("FDTDHIP_MARCH_BAND");
+    return !e || atoi(e) != 0;
+  }();
+  m.band = banded && tiles >= 16 ? (tiles + 7) / 8 : 0;
+  const dim3 grid(m.band ? 8 * m.band : tiles, (p->nx + lx - 1) / lx, 1), block(64 * waves);
   const bool constants = p->mat_const[0] && p->mat_const[1];
   // (a kernel limited to 8 waves per workgroup may use 256 registers, one for z rows of up to
   // 1024 cells 128)

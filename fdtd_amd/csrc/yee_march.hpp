@@ -44,6 +44,7 @@ template <typename T>
 struct MarchArgs {
   StepArgs<T> s;
   int lx;          // planes per chunk
+  int band;        // tiles per XCD (grid x = 8 * band), or 0: tile = blockIdx.x
 };
 
 // Additive point sources on the new E of one cell (reference fdtd/grid.py:293-295).
@@ -70,7 +71,13 @@ __global__ __launch_bounds__(64 * MW) void step_march(MarchArgs<T> ma) {
   const int k = w * 64 + lane;
   const int nx = A.nx, ny = A.ny, nz = A.nz;
   const bool kin = k < nz;
-  const int j0 = blockIdx.x * TY;
+  // Workgroups are dealt to the 8 XCDs round robin; tile t goes to XCD t % 8 unless
+  // re-mapped.  With `band` tiles per XCD, XCD x takes the tiles [x band, (x+1) band): the
+  // rows a tile reads above and below its own were then fetched into the same L2 by the
+  // neighbouring tiles, which run at about the same planes.
+  const int tile = ma.band > 0 ? (int)(blockIdx.x & 7) * ma.band + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (tile * TY >= ny) return;
+  const int j0 = tile * TY;
   const int i0 = blockIdx.y * ma.lx, i1 = min(i0 + ma.lx, nx);
   const int64_t sy = 3 * (int64_t)nz, sx = sy * ny;
   const T* __restrict__ H0 = A.G;

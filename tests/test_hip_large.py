@@ -322,3 +322,79 @@ def test_long_run_against_oracle(dtype):
     assert rel_l2(host(g.E), o.E) <= TOL[dtype]
     assert rel_l2(host(g.H), o.H) <= TOL[dtype]
     assert rel_l2(host(det.E), np.array(odet.E)) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype,shape", [("float32", (100, 170, 250)), ("float32", (96, 128, 1024)),
+                                         ("float64", (99, 170, 260))],
+                         ids=["f32-ragged", "f32-1024-cell-rows", "f64-ragged"])
+def test_whole_step_marching_kernel_equals_half_steps_bitwise(dtype, shape):
+    """Large 3-D grids without PMLs take whole steps in one launch (workgroups marching along
+    x, out of place).  The same scene advanced by `run` (marching kernel, an odd number of
+    steps so that a last step of two half-step launches follows the pairs) and by explicit
+    half steps must give identical bits: fields, detector records; and both must match the
+    oracle.  Extents that are no multiples of the tile height, the wave width or the chunk
+    length; objects of every kind, several sources, random start fields and materials that
+    the scan proves constant (float32 ragged, float64) or not (1024-cell rows)."""
+    fdtd.set_backend(f"hip.{dtype}")
+    nx, ny, nz = shape
+    rs = np.random.RandomState(21)
+    E0, H0 = 1e-2 * rs.randn(*shape, 3), 1e-2 * rs.randn(*shape, 3)
+    dense = nz == 1024
+    ie = 1.0 / (1 + rs.rand(*shape, 3)) if dense else None
+    steps = 7
+
+    def build():
+        g = fdtd.Grid(shape)
+        g.E, g.H = fdtd.backend.array(E0), fdtd.backend.array(H0)
+        if dense:
+            g.inverse_permittivity = fdtd.backend.array(ie)
+        g[10:30, 40:90, 60:150] = fdtd.Object(permittivity=2.1)
+        ani = fdtd.AnisotropicObject(permittivity=1.8)
+        g[25:50, 20:60, 100:190] = ani
+        off = 0.03 * np.random.RandomState(4).randn(25, 40, 90, 3, 3)
+        with torch.no_grad():
+            ani.inverse_permittivity += fdtd.backend.array(off)
+        g[40:60, 70:120, 30:80] = fdtd.AbsorbingObject(permittivity=1.5, conductivity=3e-3)
+        for cell, period in (((nx // 2, ny // 2, nz // 2), 11), ((0, 0, 0), 7), ((nx - 1, ny - 1, nz - 1), 9),
+                             ((33, 64, 63), 13), ((33, 64, 64), 5)):
+            g[cell] = fdtd.PointSource(period=period)
+        det = fdtd.LineDetector()
+        g[5:65, 64, 64] = det
+        return g, det, off
+
+    import ctypes
+
+    a, da, off = build()
+    a._provide_step_buffers()
+    lib = a._ensure_plan()
+    _lib.check(lib.fdtdhip_plan_enable_timing(a._plan, 1))
+    a.run(steps, progress_bar=False)
+    msE, nE, msH, nH = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
+    _lib.check(lib.fdtdhip_plan_get_timing(a._plan, ctypes.byref(msE), ctypes.byref(nE),
+                                            ctypes.byref(msH), ctypes.byref(nH)))
+    _lib.check(lib.fdtdhip_plan_enable_timing(a._plan, 0))
+    # six whole-step launches (counted with the E launches) and one step of two half steps
+    assert (nE.value, nH.value) == (steps, 1), "the marching kernel did not run"
+    b, db, _ = build()
+    for _ in range(steps):
+        b.update_E()
+        b.update_H()
+        b.time_steps_passed += 1
+    torch.cuda.synchronize()
+    assert float(a.E.abs().max()) > 0
+    assert torch.equal(a.E, b.E) and torch.equal(a.H, b.H)
+    assert torch.equal(torch.stack(list(da.E)), torch.stack(list(db.E)))
+    assert torch.equal(torch.stack(list(da.H)), torch.stack(list(db.H)))
+    if nz == 1024:
+        return      # (the oracle comparison of the other two shapes covers the arithmetic)
+    o = orc.OracleGrid(shape)
+    o.E[...], o.H[...] = E0, H0
+    o.add_object((10, 30, 40, 90, 60, 150), 2.1)
+    oa = o.add_object((25, 50, 20, 60, 100, 190), 1.8, kind="anisotropic")
+    oa.inverse_permittivity += off
+    o.add_object((40, 60, 70, 120, 30, 80), 1.5, kind="absorbing", conductivity=3e-3)
+    for cell, period in (((nx // 2, ny // 2, nz // 2), 11), ((0, 0, 0), 7), ((nx - 1, ny - 1, nz - 1), 9),
+                         ((33, 64, 63), 13), ((33, 64, 64), 5)):
+        o.add_point_source(cell, period=period)
+    o.run(steps)
+    assert rel_l2(host(a.E), o.E) <= TOL[dtype] and rel_l2(host(a.H), o.H) <= TOL[dtype]

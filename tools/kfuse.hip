@@ -244,7 +244,7 @@ int main(int argc, char** argv) {
     e.bg[0] = 1.0f; e.bg[1] = 0.9f; e.bg[2] = 0.8f;
     h.bg[0] = 0.7f; h.bg[1] = 1.0f; h.bg[2] = 0.95f;
     la.s.E1 = E1; la.s.H1 = H1; la.s.nsrc = 0; la.s.detmap = nullptr;
-    la.lx = lx;
+    la.lx = lx; la.band = 0;
   }
   auto go = [&]() {
     if (ty == 0) {
