@@ -17,6 +17,12 @@ Differentiable inputs: ``grid.E``, ``grid.H``, the PML memory variables (so that
 consecutive runs chain) and ``obj.inverse_permittivity`` of anisotropic objects
 that require grad.  Material arrays of the grid and sources are constants.
 
+Half steps driven by hand (``grid.update_E()`` / ``grid.update_H()``, as reference
+tests/test_detectors.py:62-70 does, possibly with writes into the fields in between) are
+recorded the same way, one node per half step (the reference records them like any other
+operation: fdtd/grid.py:275-325 under fdtd/backend.py:57-59); its backward is the adjoint
+of that half step alone (``fdtdhip_adjoint_cells`` + ``fdtdhip_adjoint_gather``).
+
 On x-slabs (``fdtd_amd.parallel.SlabGrid``) every rank records the same chain of
 nodes for its planes; the reverse sweep exchanges one plane of difference adjoints
 with a neighbour per half step, so ``backward`` is a collective: every rank must
@@ -68,8 +74,12 @@ def _ptr(t):
 
 
 class _Run(torch.autograd.Function):
+    """``n`` full steps (n > 0), or one half step: n = -1 the E half step, n = -2 the H one."""
+
     @staticmethod
     def forward(ctx, grid, n, E, H, *rest):
+        half, n = (None, n) if n > 0 else ("E" if n == -1 else "H", 1)
+        ctx.half = half
         objs, pmls = _learnable(grid), _active_pmls(grid)
         mods = _modulated(objs)
         srcs = _modulated_sources(grid)   # native ids known: the caller prepared the plan
@@ -102,7 +112,10 @@ class _Run(torch.autograd.Function):
             src._recording = (*state, None, None, None, q0)
             src_state.append(state)
         try:
-            grid._native_run(lib, n)
+            if half is None:
+                grid._native_run(lib, n)
+            else:
+                grid._native_half_step(lib, half == "E")
         finally:
             for src in srcs:
                 src._recording = None
@@ -157,7 +170,13 @@ class _Run(torch.autograd.Function):
                                                             _ptr(gm)))
             gmods.append(gm)
         try:
-            grid._native_adjoint(lib, n, lamE, lamH, work)
+            if ctx.half is None:
+                grid._native_adjoint(lib, n, lamE, lamH, work)
+            else:
+                # the adjoint of that half step alone: per-cell pass, then the gather
+                phase = 1 if ctx.half == "E" else 0
+                _lib.check(lib.fdtdhip_adjoint_cells(plan, phase, 0, _ptr(lamE), _ptr(lamH), _ptr(work)))
+                _lib.check(lib.fdtdhip_adjoint_gather(plan, phase, _ptr(lamE), _ptr(lamH), _ptr(work), None))
         finally:
             for o in objs:
                 _lib.check(lib.fdtdhip_plan_set_object_trace(plan, o._native_id, None, 0))
@@ -183,9 +202,14 @@ class _Run(torch.autograd.Function):
         return (None, None, lamE, lamH, *grads, *wgrads, *sgrads, *lam_psi)
 
 
+def differentiable_half_step(grid, phase_E):
+    """One half step recorded as an autograd node (the step counter is the caller's)."""
+    differentiable_advance(grid, -1 if phase_E else -2)
+
+
 def differentiable_advance(grid, n):
-    """``n`` full steps recorded as one autograd node; re-binds the grid's state tensors
-    to the node's outputs."""
+    """``n`` full steps (or, n < 0, one half step) recorded as one autograd node; re-binds
+    the grid's state tensors to the node's outputs."""
     for src in grid.sources:
         if getattr(src, "_no_autograd", None):
             raise NotImplementedError(f"differentiable runs do not cover {src._no_autograd}")
@@ -199,7 +223,7 @@ def differentiable_advance(grid, n):
     if any(hasattr(s, "_torch_inputs") for s in grid.sources):
         grid._ensure_plan()  # decides which sources have cells on this rank
     for src in _modulated_sources(grid):
-        P, osc = src._torch_inputs(grid.time_steps_passed, n)
+        P, osc = src._torch_inputs(grid.time_steps_passed, max(n, 1))
         inputs += [P, osc, src.nonlin_conv.weight, src.nonlin_conv.bias]
     for p in pmls:
         inputs += [p._psiE, p._psiH]
@@ -207,4 +231,5 @@ def differentiable_advance(grid, n):
     grid.E, grid.H = out[0], out[1]
     for n_p, p in enumerate(pmls):
         p._psiE, p._psiH = out[2 + 2 * n_p], out[3 + 2 * n_p]
-    grid.time_steps_passed += n
+    if n > 0:
+        grid.time_steps_passed += n

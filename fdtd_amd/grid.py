@@ -423,32 +423,46 @@ class Grid:
     # --------------------------------------------------------------- stepping
     def update_E(self):
         """One electric half step (reference fdtd/grid.py:275-299)."""
-        self._no_half_step_autograd()
-        lib = self._ensure_plan()
-        self._prepare_sources(lib, 1)
-        for det in self.detectors:
-            det._reserve(lib, self._plan, 1, 0)
-        _lib.check(lib.fdtdhip_update_E(self._plan, self.time_steps_passed))
-        for det in self.detectors:
-            det._commit(1, 0)
-        self._finish_sources(1)
+        if self._half_step_recorded(True):
+            return
+        self._native_half_step(self._ensure_plan(), True)
 
     def update_H(self):
         """One magnetic half step (reference fdtd/grid.py:301-325)."""
-        self._no_half_step_autograd()
-        lib = self._ensure_plan()
+        if self._half_step_recorded(False):
+            return
+        self._native_half_step(self._ensure_plan(), False)
+
+    def _native_half_step(self, lib, phase_E):
+        """One half step at ``time_steps_passed`` on the prepared plan."""
+        if phase_E:
+            self._prepare_sources(lib, 1)
+        nE, nH = (1, 0) if phase_E else (0, 1)
         for det in self.detectors:
-            det._reserve(lib, self._plan, 0, 1)
-        _lib.check(lib.fdtdhip_update_H(self._plan, self.time_steps_passed))
+            det._reserve(lib, self._plan, nE, nH)
+        fn = lib.fdtdhip_update_E if phase_E else lib.fdtdhip_update_H
+        _lib.check(fn(self._plan, self.time_steps_passed))
         for det in self.detectors:
-            det._commit(0, 1)
+            det._commit(nE, nH)
+        if phase_E:
+            self._finish_sources(1)
+
+    def _half_step_recorded(self, phase_E):
+        """When gradients are wanted, record the half step as an autograd node."""
+        from . import autograd
+
+        if bd.staging or not autograd.needs_grad(self):
+            return False
+        autograd.differentiable_half_step(self, phase_E)
+        return True
 
     def _no_half_step_autograd(self):
+        """x-slabs record whole steps only (their reverse sweep is driven per step)."""
         from . import autograd
 
         if not bd.staging and autograd.needs_grad(self):
             raise NotImplementedError(
-                "gradients are recorded per full step: call grid.step() / grid.run(n) "
+                "on x-slabs gradients are recorded per full step: call grid.step() / grid.run(n) "
                 "(or wrap the half steps in torch.no_grad())")
 
     def step(self):

@@ -102,8 +102,73 @@ def test_no_grad_run_leaves_no_graph():
     assert grid.E.grad_fn is None and not grid.E.requires_grad
     grid.run(5, progress_bar=False)
     assert grid.E.grad_fn is not None
-    with pytest.raises(NotImplementedError):
+    grid.update_E()                      # half steps are recorded too
+    assert grid.E.grad_fn is not None
+
+
+@pytest.mark.parametrize("name", ["adjoint_focus2d", "adjoint_pml3d", "adjoint_substrate2d", "adjoint_cortical2d_b"])
+def test_half_steps_driven_by_hand_give_the_reference_gradients(name):
+    """grid.update_E() / grid.update_H() under autograd (reference tests/test_detectors.py:62-70
+    drives the grid that way; the reference records every operation, fdtd/backend.py:57-59):
+    the first chunk of the scene advanced by explicit half steps, the rest by run(), must
+    give the gradients of the reference's autograd for the whole run."""
+    fdtd.set_backend("hip.float64")
+    scene = scenes.ADJOINT_SCENES[name]
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    grid, made = scenes.build_api(scene, fdtd)
+    by_hand = scene["chunks"][0] if len(scene["chunks"]) > 1 else scene["steps"] // 2
+    for _ in range(by_hand):
         grid.update_E()
+        grid.update_H()
+        grid.time_steps_passed += 1
+    grid.run(scene["steps"] - by_hand, progress_bar=False)
+    loss = scenes.adjoint_loss(scene, grid, torch)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel_l2(grid.E.detach().cpu().numpy(), z["E"]) <= 1e-12
+    assert abs(loss.item() - float(z["loss"])) <= 1e-11 * abs(float(z["loss"]))
+    seen = 0
+    for n, (kind, t, _, _) in enumerate(made):
+        if kind in ("learnable", "substrate"):
+            err = rel_l2(t.inverse_permittivity.grad.cpu().numpy(), z[f"grad{n}"])
+            assert err <= 1e-10, f"{name}: object {n} gradient rel-L2 {err:.3e}"
+            seen += 1
+        if kind == "substrate":
+            assert rel_l2(t.nonlin_conv.weight.grad.cpu().numpy(), z[f"gradw{n}"]) <= 1e-10
+        if kind == "cortical":
+            for key, leaf in t.leaves.items():
+                err = rel_l2(leaf.grad.cpu().numpy(), z[f"src{n}_{key}"])
+                assert err <= 1e-10, f"{name}: source {key} gradient rel-L2 {err:.3e}"
+    assert seen
+
+
+def test_field_write_between_recorded_half_steps():
+    """A value written into E between the half steps (reference tests/test_detectors.py:64-68)
+    is part of the recorded computation: the loss's derivative with respect to that value,
+    from autograd, equals the finite difference."""
+    fdtd.set_backend("hip.float64")
+
+    def run(v):
+        g = fdtd.Grid((14, 13, 12))
+        g[0:3, :, :] = fdtd.PML()
+        g[4:9, 3:8, 2:9] = fdtd.LearnableAnisotropicObject(permittivity=2.0)
+        g[7, 6, 6] = fdtd.PointSource(period=8)
+        poke = torch.tensor(v, dtype=torch.float64, device=g.E.device, requires_grad=True)
+        for s in range(6):
+            g.update_E()
+            if s == 2:
+                g.E[5, 6, 7, 1] = poke * 1.0
+            g.update_H()
+            g.time_steps_passed += 1
+        return (g.E ** 2).sum() + (g.H ** 2).sum(), poke
+
+    loss, poke = run(0.3)
+    loss.backward()
+    h = 1e-6
+    with torch.no_grad():
+        lp, lm = run(0.3 + h)[0].item(), run(0.3 - h)[0].item()
+    numeric = (lp - lm) / (2 * h)
+    assert abs(poke.grad.item() - numeric) <= 1e-6 * abs(numeric), (poke.grad.item(), numeric)
 
 
 def test_substrate_forward_without_grad():
