@@ -340,7 +340,8 @@ def DomainBorderPML(grid, border_cells=5):
     """Wrap the whole domain in PMLs of ``border_cells`` cells, with the non-overlapping
     slicing of the reference (fdtd/boundaries.py:617-645).  Alters ``grid`` in place."""
     b = border_cells
-    if min(grid.Nx, grid.Ny, grid.Nz) < 2 * b:
+    # (an x-slab checks the extent of the whole simulation, like the other ranks)
+    if min(getattr(grid, "Nx_global", grid.Nx), grid.Ny, grid.Nz) < 2 * b:
         raise IndexError("PML border_cells larger than domain!")
     grid[:, :, 0:b] = PML()
     grid[:, :, -b:] = PML()

@@ -90,8 +90,8 @@ class Grid:
         full = (self.Nx, self.Ny, self.Nz, 3)
         self.E = bd.zeros(full)
         self.H = bd.zeros(full)
-        self.inverse_permittivity = bd.ones(full) / self._material(permittivity)
-        self.inverse_permeability = bd.ones(full) / self._material(permeability)
+        self.inverse_permittivity = bd.ones(full) / self._local_planes(self._material(permittivity))
+        self.inverse_permeability = bd.ones(full) / self._local_planes(self._material(permeability))
 
         self.time_steps_passed = 0
         self.sources = []
@@ -113,6 +113,18 @@ class Grid:
         lo = max(start - self.x_offset, 0)
         hi = min(stop - self.x_offset, self.Nx)
         return lo, max(lo, hi)
+
+    def _local_planes(self, value):
+        """An array-valued material given for the whole simulation -> this grid's x planes
+        (x-slabs keep their own range; scalars and arrays of one plane pass through)."""
+        if torch.is_tensor(value) and value.dim() >= 1 and self.Nx != self.Nx_global:
+            if value.shape[0] == self.Nx_global:
+                return value[self.x_offset:self.x_offset + self.Nx]
+            if value.shape[0] != 1:
+                raise ValueError(
+                    f"material array with {value.shape[0]} x planes: an x-slab grid takes arrays of the "
+                    f"whole simulation ({self.Nx_global} planes) or of one plane")
+        return value
 
     def _planes_of_end_slab(self, side):
         """Number of x planes of the slab that holds the "low" / "high" x face of the

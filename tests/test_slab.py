@@ -268,6 +268,51 @@ def test_x_pml_thicker_than_its_slab_is_refused_on_every_rank(tmp_path):
     assert len(lines) == 2 and all(line.startswith("IndexError: PML thicker") for line in lines), lines
 
 
+def _material_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+
+    import fdtd_amd as fdtd
+    from fdtd_amd.parallel import SlabGrid
+
+    slab_support.init_gloo(rank, world, port)
+    try:
+        fdtd.set_backend("hip.float64", device="host-staging")
+        eps = 1.0 + torch.arange(11 * 8 * 3, dtype=torch.float64).reshape(11, 8, 3) / 50
+        grid = SlabGrid((11, 8, 3), permittivity=eps, permeability=eps[:1] + 1,
+                        engine_factory=slab_support.OracleSlabEngine)
+        lo, hi = grid.x_offset, grid.x_offset + grid.Nx
+        ok = bool(torch.equal(grid.inverse_permittivity, (1 / eps[lo:hi])[..., None].expand(-1, -1, -1, 3)))
+        ok = ok and bool(torch.equal(grid.inverse_permeability,
+                                     (1 / (eps[:1] + 1))[..., None].expand(grid.Nx, -1, -1, 3)))
+        seen = "sliced" if ok else "wrong planes"
+        try:
+            SlabGrid((11, 8, 3), permittivity=eps[:5], engine_factory=slab_support.OracleSlabEngine)
+            seen += ", part accepted"
+        except ValueError:
+            seen += ", part refused"
+        try:
+            # 2 * 5 cells fit the 11 planes of the simulation, not one slab's 6 or 5
+            fdtd.DomainBorderPML(SlabGrid((11, 12, 10), engine_factory=slab_support.OracleSlabEngine), 5)
+            seen += ", border sized by the simulation"
+        except IndexError as e:
+            seen += f", border: {e}"
+        everyone = [None] * world
+        dist.all_gather_object(everyone, seen)
+        if rank == 0:
+            with open(out, "w") as f:
+                f.write("\n".join(everyone))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_array_materials_of_the_whole_simulation_are_cut_to_the_slab(tmp_path):
+    out = str(tmp_path / "materials.txt")
+    mp.spawn(_material_worker, args=(2, slab_support.free_port(), out), nprocs=2, join=True)
+    lines = open(out).read().splitlines()
+    assert lines == ["sliced, part refused, border sized by the simulation"] * 2, lines
+
+
 def _fuzz(world, first, count, on_gpu, tmp_path, crowded=False):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_slab
