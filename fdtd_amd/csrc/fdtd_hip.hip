@@ -1127,7 +1127,7 @@ FusedKind fused_kind(const fdtdhip_plan* p) {
   // cells (161 x 97: 9.0 against 11.4 us per step, 360^2: 12.7 / 14.1, 420^2: 15.4 / 15.7,
   // 512^2: 17.7 / 17.1; in 3-D the lane's four E evaluations with six faces cost more than
   // the second launch at every size tried, and on large grids the kernel is L1-bound), and
-  // step_march on 3-D grids without PMLs, with z rows of 128 to 1024 cells and enough rows and
+  // step_march on 3-D grids without PMLs and objects, with z rows of 128 to 1024 cells and enough rows and
   // planes to fill the machine with workgroups (512^3 float32: 1.25 against 1.66 ms per step,
   // 256^3: 0.187 against 0.21, 256 x 1024 x 1024: 2.67 against 3.3; float64 512^3: 3.05 / 3.34).
   static const int mode = [] {
@@ -1155,7 +1155,10 @@ FusedKind fused_kind(const fdtdhip_plan* p) {
   if (mode == 2) return march_ok ? FUSED_MARCH : FUSED_NONE;
   const int thin = std::min(p->nx, std::min(p->ny, p->nz));
   if (cell_ok && p->cells() <= FUSED_AUTO_MAX_CELLS && thin == 1) return FUSED_CELL;
-  if (march_ok && p->nz >= 128 && p->ny >= 64 && p->nx >= 64 && p->cells() >= (1ll << 22))
+  // (with objects the kernel needs 130 registers -- one workgroup of eight waves per CU -- and
+  // its loads wait for one another: 512^3 float32, two 64^3 boxes: 2.08 against 1.63 ms)
+  if (march_ok && p->objs.empty() && p->nz >= 128 && p->ny >= 64 && p->nx >= 64 &&
+      p->cells() >= (1ll << 22))
     return FUSED_MARCH;
   return FUSED_NONE;
 }

@@ -324,17 +324,43 @@ def test_long_run_against_oracle(dtype):
     assert rel_l2(host(det.E), np.array(odet.E)) <= TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype,shape", [("float32", (100, 170, 250)), ("float32", (96, 128, 1024)),
-                                         ("float64", (99, 170, 260))],
-                         ids=["f32-ragged", "f32-1024-cell-rows", "f64-ragged"])
+_MARCH_CASES = [("float32", (100, 170, 250)), ("float32", (96, 128, 1024)), ("float64", (99, 170, 260))]
+_MARCH_IDS = ["f32-ragged", "f32-1024-cell-rows", "f64-ragged"]
+
+
+@pytest.mark.parametrize("dtype,shape", _MARCH_CASES, ids=_MARCH_IDS)
 def test_whole_step_marching_kernel_equals_half_steps_bitwise(dtype, shape):
-    """Large 3-D grids without PMLs take whole steps in one launch (workgroups marching along
-    x, out of place).  The same scene advanced by `run` (marching kernel, an odd number of
-    steps so that a last step of two half-step launches follows the pairs) and by explicit
-    half steps must give identical bits: fields, detector records; and both must match the
-    oracle.  Extents that are no multiples of the tile height, the wave width or the chunk
-    length; objects of every kind, several sources, random start fields and materials that
+    """Large 3-D grids without PMLs and objects take whole steps in one launch (workgroups
+    marching along x, out of place).  The same scene advanced by `run` (marching kernel, an odd
+    number of steps so that a last step of two half-step launches follows the pairs) and by
+    explicit half steps must give identical bits: fields, detector records; and both must
+    match the oracle.  Extents that are no multiples of the tile height, the wave width or the
+    chunk length; several sources, random start fields and materials that
     the scan proves constant (float32 ragged, float64) or not (1024-cell rows)."""
+    _march_case(dtype, shape, objects=False)
+
+
+def test_whole_step_marching_kernel_with_objects_forced():
+    """The marching kernel's object variant (objects of every kind) is not what the library
+    picks by default -- two half-step launches are faster there -- but FDTDHIP_FUSED=2 applies
+    it: same bitwise checks as above.  The switch is read once per process, hence the child."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (f"import sys\nsys.path[:0] = [{os.path.dirname(here)!r}, {here!r}]\n"
+            "import test_hip_large as t\n"
+            "for dtype, shape in t._MARCH_CASES:\n"
+            "    t._march_case(dtype, shape, objects=True)\n"
+            "print('marched with objects')\n")
+    done = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FDTDHIP_FUSED="2"),
+                          capture_output=True, text=True, timeout=280, cwd=here)
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
+    assert "marched with objects" in done.stdout
+
+
+def _march_case(dtype, shape, objects):
     fdtd.set_backend(f"hip.{dtype}")
     nx, ny, nz = shape
     rs = np.random.RandomState(21)
@@ -348,13 +374,14 @@ def test_whole_step_marching_kernel_equals_half_steps_bitwise(dtype, shape):
         g.E, g.H = fdtd.backend.array(E0), fdtd.backend.array(H0)
         if dense:
             g.inverse_permittivity = fdtd.backend.array(ie)
-        g[10:30, 40:90, 60:150] = fdtd.Object(permittivity=2.1)
-        ani = fdtd.AnisotropicObject(permittivity=1.8)
-        g[25:50, 20:60, 100:190] = ani
         off = 0.03 * np.random.RandomState(4).randn(25, 40, 90, 3, 3)
-        with torch.no_grad():
-            ani.inverse_permittivity += fdtd.backend.array(off)
-        g[40:60, 70:120, 30:80] = fdtd.AbsorbingObject(permittivity=1.5, conductivity=3e-3)
+        if objects:
+            g[10:30, 40:90, 60:150] = fdtd.Object(permittivity=2.1)
+            ani = fdtd.AnisotropicObject(permittivity=1.8)
+            g[25:50, 20:60, 100:190] = ani
+            with torch.no_grad():
+                ani.inverse_permittivity += fdtd.backend.array(off)
+            g[40:60, 70:120, 30:80] = fdtd.AbsorbingObject(permittivity=1.5, conductivity=3e-3)
         for cell, period in (((nx // 2, ny // 2, nz // 2), 11), ((0, 0, 0), 7), ((nx - 1, ny - 1, nz - 1), 9),
                              ((33, 64, 63), 13), ((33, 64, 64), 5)):
             g[cell] = fdtd.PointSource(period=period)
@@ -389,10 +416,11 @@ def test_whole_step_marching_kernel_equals_half_steps_bitwise(dtype, shape):
         return      # (the oracle comparison of the other two shapes covers the arithmetic)
     o = orc.OracleGrid(shape)
     o.E[...], o.H[...] = E0, H0
-    o.add_object((10, 30, 40, 90, 60, 150), 2.1)
-    oa = o.add_object((25, 50, 20, 60, 100, 190), 1.8, kind="anisotropic")
-    oa.inverse_permittivity += off
-    o.add_object((40, 60, 70, 120, 30, 80), 1.5, kind="absorbing", conductivity=3e-3)
+    if objects:
+        o.add_object((10, 30, 40, 90, 60, 150), 2.1)
+        oa = o.add_object((25, 50, 20, 60, 100, 190), 1.8, kind="anisotropic")
+        oa.inverse_permittivity += off
+        o.add_object((40, 60, 70, 120, 30, 80), 1.5, kind="absorbing", conductivity=3e-3)
     for cell, period in (((nx // 2, ny // 2, nz // 2), 11), ((0, 0, 0), 7), ((nx - 1, ny - 1, nz - 1), 9),
                          ((33, 64, 63), 13), ((33, 64, 64), 5)):
         o.add_point_source(cell, period=period)
