@@ -18,8 +18,9 @@
 // L1/L2 hits; HBM sees each array once.  Those 26 loads per lane make the kernel
 // L1-bound on large grids (512^3 fp32: 3.2 ms a step against 2.2 ms for two half
 // steps), so the plan uses it where launch count decides the step time: small
-// grids.  A marching variant that carried planes in registers and exchanged
-// neighbours through LDS cut the loads to 8 per cell but its strided 756-byte row
+// grids (large 3-D grids take step_march of yee_march.hpp instead, which marches along x
+// over whole z rows).  A first marching variant over 64-cell z segments, planes in registers
+// and neighbours through LDS, cut the loads to 8 per cell but its strided 756-byte row
 // segments cost more DRAM efficiency than the saved traffic returned (2.33 ms); a
 // variant of this kernel that staged the neighbourhood of a 4-row x 64-cell tile in LDS
 // (7 coalesced cell loads per lane) also took 2.33 ms with constant materials, against
