@@ -15,7 +15,9 @@ fdtd/objects.py:315-349).  Here a run of ``n`` steps is a single
 
 Differentiable inputs: ``grid.E``, ``grid.H``, the PML memory variables (so that
 consecutive runs chain) and ``obj.inverse_permittivity`` of anisotropic objects
-that require grad.  Material arrays of the grid and sources are constants.
+that require grad.  Material arrays of the grid and sources are constants; the feedback of
+a ``SoftArbitraryPointSource`` (its voltage depends on H through its loop current) is part
+of the adjoint.
 
 Half steps driven by hand (``grid.update_E()`` / ``grid.update_H()``, as reference
 tests/test_detectors.py:62-70 does, possibly with writes into the fields in between) are
@@ -163,6 +165,9 @@ class _Run(torch.autograd.Function):
             src._recording = (P, osc, wb, trace, gP, gosc, gwb, ctx.q0)
             src._native_prepare(lib, plan, ctx.q0, n)
             src_grads.append((gP, gosc, gwb))
+        for src in grid.sources:   # sources fed back from their loop current: the run's first time step
+            if hasattr(src, "current_detector") and getattr(src, "_native_id", None) is not None:
+                _lib.check(lib.fdtdhip_plan_set_soft_source_adjoint(plan, src._native_id, ctx.q0))
         gmods = []
         for o, et, wb in zip(mods, ctx.etraces, ctx.mod_weights):
             gm = bd.zeros((o.Nx * o.Ny * o.Nz, 9, 3))

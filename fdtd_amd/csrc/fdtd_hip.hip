@@ -121,6 +121,7 @@ struct SourceH {
   const void* prev_current = nullptr;  // last reading taken before this run, or null
   char *vin = nullptr, *vout = nullptr;
   int64_t vcap = 0, vused = 0;
+  int64_t adj_q0 = -1;         // time step of row 0 of the adjoint calls (fdtdhip_plan_set_soft_source_adjoint)
 };
 
 struct DetH {
@@ -909,8 +910,19 @@ int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
   // that follow the first periodic one, last first
   for (auto it = p->sources.rbegin(); it != p->sources.rend(); ++it) {
     const SourceH& s = *it;
-    if (s.kind == FDTDHIP_SRC_SOFT_POINT)
-      return fail(-1, "the adjoint does not cover a source fed back from a current detector");
+    if (s.kind == FDTDHIP_SRC_SOFT_POINT) {
+      // the voltage added to E is a constant plus impedance * (loop current of the step
+      // before): its adjoint goes to the adjoint of H as the H half step before left it
+      if (!phaseE || s.nwave < 0 || !(s.impedance > 0)) continue;
+      if (p->H_below || p->E_above)
+        return fail(-1, "the adjoint does not cover a source fed back from a current detector on x-slabs");
+      if (s.adj_q0 < 0)
+        return fail(-1, "soft source: fdtdhip_plan_set_soft_source_adjoint names the time step of the adjoint's row 0");
+      if (s.adj_q0 + p->trace_cursor <= 0) continue;   // no current yet at time step 0
+      hipLaunchKernelGGL((adj_source_soft_point<T>), dim3(1), dim3(1), 0, p->stream, (const T*)lamE,
+                         lamH, s.elem0, p->nx, p->ny, p->nz, s.impedance, s.spacing);
+      continue;
+    }
     if (s.kind == FDTDHIP_SRC_MODULATED_BOX && phaseE && s.modP) {
       const int64_t row = p->trace_cursor;
       const int64_t cells =
@@ -1715,6 +1727,14 @@ int fdtdhip_plan_set_soft_source_io(fdtdhip_plan* p, int id, const void* prev_cu
   s.prev_current = prev_current;
   s.vin = (char*)vin_out; s.vout = (char*)vout_out;
   s.vcap = capacity; s.vused = 0;
+  return 0;
+}
+
+int fdtdhip_plan_set_soft_source_adjoint(fdtdhip_plan* p, int id, int64_t q0) {
+  if (!p) return fail(-1, "null plan");
+  if (id < 0 || id >= (int)p->sources.size() || p->sources[id].kind != FDTDHIP_SRC_SOFT_POINT)
+    return fail(-1, "not a soft source");
+  p->sources[id].adj_q0 = q0;
   return 0;
 }
 

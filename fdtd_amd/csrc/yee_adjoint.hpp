@@ -533,6 +533,34 @@ __global__ void adj_periodic_copy(T* lam, int nx, int ny, int nz, int axis, int 
 //   gosc[c]         = sum lam * P * mod           (this step's row)
 //   gwb[c][0..2]   += sum dz * {eE, eH, 1},  dz = lam * osc[c] * P * mod * (1 - mod)
 // Sums over cells go through a fixed LDS tree: reproducible.
+// Adjoint of the voltage source fed back from its loop current (source_soft_point with
+// detect_current of yee_generic.hpp; reference fdtd/sources.py:719-734 and
+// fdtd/detectors.py:443-464): E[cell, z] took impedance * I / spacing, and I is the linear
+// form of H around the cell that detect_current evaluates -- with the first layer's Hy
+// difference counted in both layers and Python's wrap-around for index -1.  One lane;
+// coinciding cells (an extent of one) just receive several of the terms.
+template <typename T>
+__global__ void adj_source_soft_point(const T* lamE, T* lamH, int64_t elem, int nx, int ny, int nz,
+                                      double impedance, double spacing) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const int64_t cell = elem / 3;
+  const int pz = (int)(cell % nz), py = (int)((cell / nz) % ny), px = (int)(cell / ((int64_t)nz * ny));
+  const int xm = px == 0 ? nx - 1 : px - 1;
+  const int ym = py == 0 ? ny - 1 : py - 1;
+  const int zm = pz == 0 ? nz - 1 : pz - 1;
+  auto at = [&](int i, int j, int k, int c) -> T& {
+    return lamH[(((int64_t)i * ny + j) * nz + k) * 3 + c];
+  };
+  // adjoint of the current, then of each of its two layers (I = (cur1 + cur2) / 2), times
+  // the spacing every difference was scaled with
+  const T g = (T)((double)lamE[elem] * (impedance / spacing));
+  const T h = g / T(2) * (T)spacing;
+  at(px, ym, pz, 0) += h; at(px, py, pz, 0) -= h;            // layer pz, Hx
+  at(px, py, pz, 1) += h + h; at(xm, py, pz, 1) -= h + h;    // layer pz, Hy: in both currents
+  at(px, ym, zm, 0) += h; at(px, py, zm, 0) -= h;            // layer pz - 1, Hx
+  at(px, py, zm, 1) += h; at(xm, py, zm, 1) -= h;            // layer pz - 1, Hy
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void adj_source_modulated(
     const T* lamE, int ny, int nz, int x0, int x1, int y0, int y1, int z0, int z1, int comp,

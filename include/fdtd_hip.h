@@ -181,12 +181,18 @@ int fdtdhip_plan_set_modulated_source(fdtdhip_plan* plan, int id, const void* P,
  * fdtdhip_plan_set_soft_source_io, before a run: prev_current = device address of that
  * detector's last reading taken before this run (first point; NULL: none yet), and two
  * device arrays of the plan's element type with room for `capacity` steps that receive
- * v_in and v_out of every step (the reference's input_voltage / source_voltage lists). */
+ * v_in and v_out of every step (the reference's input_voltage / source_voltage lists).
+ * Differentiable runs (the reference has the feedback on torch's tape: the current read at
+ * sources.py:720 is a function of H): fdtdhip_plan_set_soft_source_adjoint, before
+ * fdtdhip_adjoint_run / _cells, names the time step q0 of the adjoint's step 0 (at time step 0
+ * there is no current); the adjoint of E at the cell then reaches the adjoint of H around
+ * it.  Not on x-slabs.  The waveform is a constant (no gradient for it). */
 int fdtdhip_plan_add_soft_source(fdtdhip_plan* plan, const int32_t cell[3], const double* waveform,
                                  int64_t nwave, double impedance, double spacing);
 int fdtdhip_plan_link_soft_source(fdtdhip_plan* plan, int id, int detector_id);
 int fdtdhip_plan_set_soft_source_io(fdtdhip_plan* plan, int id, const void* prev_current,
                                     void* vin_out, void* vout_out, int64_t capacity);
+int fdtdhip_plan_set_soft_source_adjoint(fdtdhip_plan* plan, int id, int64_t q0);
 
 /* Detector over n points.  FDTDHIP_DET_CELLS: cells = HOST 3*n ints; each
  * reading is (n,3) (reference fdtd/detectors.py:114-124, 241-265).

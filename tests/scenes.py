@@ -410,6 +410,24 @@ ADJOINT_SCENES = {
         steps=30, chunks=(1, 1, 1, 12, 15),
         loss=dict(kind="dense", seed=7),
     ),
+    # a voltage source with a series resistance fed back from its own loop current (reference
+    # fdtd/sources.py:708-737 with fdtd/detectors.py:443-464 on the tape), next to a learnable
+    # object; two runs, so that the first step of the second one takes its current from the
+    # state the first one left
+    "adjoint_softfeed": dict(
+        grid=dict(shape=(14, 13, 10), grid_spacing=4e-4),
+        items=[
+            ("pml",       (S(0, 3), S(None), S(None)), {}),
+            ("pml",       (S(-3, None), S(None), S(None)), {}),
+            ("pml",       (S(None), S(None), S(-3, None)), {}),
+            ("learnable", (S(4, 10), S(3, 9), S(2, 7)), dict(permittivity=2.4), dict(offdiag_seed=31, offdiag_scale=0.04)),
+            ("soft",      (7, 6, 4), dict(waveform_array=("gauss", 30, 9.0, 5.0, 1e-3), impedance=0.3)),
+            ("soft",      (5, 9, 0), dict(waveform_array=("gauss", 20, 7.0, 4.0, 5e-4), impedance=0.2)),   # z - 1 wraps around
+            ("absorbing", (S(8, 12), S(7, 11), S(3, 4)), dict(permittivity=1.0, conductivity=1e3)),
+        ],
+        steps=26, chunks=(9, 1, 16),
+        loss=dict(kind="dense", seed=9),
+    ),
     # other shapes of the same set-up: seven columns on a ragged plane that a substrate and an
     # absorbing object cover in part, PMLs along y
     "adjoint_cortical2d_b": dict(

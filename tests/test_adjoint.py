@@ -106,7 +106,8 @@ def test_no_grad_run_leaves_no_graph():
     assert grid.E.grad_fn is not None
 
 
-@pytest.mark.parametrize("name", ["adjoint_focus2d", "adjoint_pml3d", "adjoint_substrate2d", "adjoint_cortical2d_b"])
+@pytest.mark.parametrize("name", ["adjoint_focus2d", "adjoint_pml3d", "adjoint_substrate2d", "adjoint_cortical2d_b",
+                                  "adjoint_softfeed"])
 def test_half_steps_driven_by_hand_give_the_reference_gradients(name):
     """grid.update_E() / grid.update_H() under autograd (reference tests/test_detectors.py:62-70
     drives the grid that way; the reference records every operation, fdtd/backend.py:57-59):
