@@ -429,24 +429,22 @@ __global__ __launch_bounds__(256) void adj_gather(AdjArgs<T> a) {
   int i, j, k;
   if (!adj_lane_cell<T, ROWS>(a, i, j, k)) return;
   const int64_t cell = ((int64_t)i * a.ny + j) * a.nz + k;
+  T* out = a.lamG + cell * 3;
+  // The adjoint being completed is requested first, so that it travels together with the
+  // loads of the gather instead of after them (the choice between the two forms below is a
+  // branch the compiler does not move a load across).  Streamed once per launch: in float32
+  // non-temporal, to keep it out of the way of the neighbour re-reads (as the forward row
+  // kernels do for the advanced field; float64 cells gain nothing from it).
+  constexpr bool NT = ROWS && sizeof(T) == 4;
+  T o[3];
+  load3<T, NT>(out, o[0], o[1], o[2]);
   T add[3];
   if (a.direct && (PHASE_E ? adj_box_plain(a, i, i + 1, j, j + 1, k, k + 1)
                            : adj_box_plain(a, i - 1, i, j - 1, j, k - 1, k)))
     adj_gather_direct<T, PHASE_E>(a, i, j, k, add);
   else
     adj_gather_cell<T, PHASE_E>(a, i, j, k, add);
-  T* out = a.lamG + cell * 3;
-  if (ROWS && sizeof(T) == 4) {
-    // streamed once per launch: keep it out of the way of the neighbour re-reads (as the
-    // forward row kernels do for the advanced field; float64 cells gain nothing from it)
-    T o[3];
-    load3<T, true>(out, o[0], o[1], o[2]);
-    store3<T, true>(out, o[0] + add[0], o[1] + add[1], o[2] + add[2]);
-  } else {
-    out[0] += add[0];
-    out[1] += add[1];
-    out[2] += add[2];
-  }
+  store3<T, NT>(out, o[0] + add[0], o[1] + add[1], o[2] + add[2]);
 }
 
 // Small grids (one wave per SIMD, time = number of launches): pass 2 of one half step and
