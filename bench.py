@@ -319,7 +319,8 @@ def launch_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    # (half a second or more of timed kernels by default: a sampling monitor beside the run sees it)
+    ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, help="default: m3v on one GPU, m4 slabs on several")
     ap.add_argument("--materials", choices=("auto", "arrays"), default="auto")

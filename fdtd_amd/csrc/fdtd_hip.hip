@@ -691,7 +691,8 @@ int post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts = POST_ALL, int x0 =
   if (x1 < 0) x1 = p->nx;
   const int64_t plane3 = (int64_t)p->ny * p->nz * 3;
   const int64_t elem_lo = x0 * plane3, elem_hi = x1 * plane3;
-  if ((parts & POST_FINISH) && phaseE) advance_trace_cursor(p);
+  // (the row of the curl traces moves on once per E half step: not in stage 0 of a pair)
+  if ((parts & POST_FINISH) && phaseE && stage != 0) advance_trace_cursor(p);
   // stage 0 / 1: only what precedes / follows the x-periodic boundary whose copy crosses
   // ranks (the caller performs it in between); sources and the rest belong to stage 1
   size_t ext = p->boundaries.size();
@@ -896,19 +897,31 @@ int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArg
   return 0;
 }
 
+// Index of the periodic boundary along x whose two planes live on different ranks, or the
+// number of boundaries.
+size_t external_periodic(const fdtdhip_plan* p) {
+  for (size_t b = 0; b < p->boundaries.size(); ++b)
+    if (p->boundaries[b].kind == 1 && p->boundaries[b].idx == FDTDHIP_PERIODIC_X_EXTERNAL) return b;
+  return p->boundaries.size();
+}
+
+// Reverse of post(): sources (hard assignments kill the adjoint), then the boundaries that
+// follow the first periodic one, last first.  stage < 0: all of it.  With a periodic boundary
+// whose copy crosses ranks (the caller's) the work comes in two stages, as in the forward
+// pass, in reverse order: stage 1 = the sources and the boundaries registered after that
+// boundary, stage 0 = the boundaries registered before it.
 template <typename T>
-int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
+int adjoint_post(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, int stage) {
   if (!p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
-  if (!lamE || !lamH || !work) return fail(-1, "null adjoint array");
-  for (const ObjH& o : p->objs)
-    if (o.kind == FDTDHIP_OBJ_ANISOTROPIC_MODULATED && (!o.modw || !o.etrace || !o.trace))
-      return fail(-1, "the adjoint of a modulated object needs its curl and energy traces");
-  if (int rc = sync_obj_table<T>(p)) return rc;
+  if (!lamE || !lamH) return fail(-1, "null adjoint array");
   T* lamF = phaseE ? lamE : lamH;
   const T* mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
-  // reverse of post(): sources (hard assignments kill the adjoint), then the boundaries
-  // that follow the first periodic one, last first
+  const size_t ext = external_periodic(p);
+  if (stage >= 0 && ext == p->boundaries.size()) return fail(-1, "no external periodic boundary");
+  if (stage < 0 && ext != p->boundaries.size())
+    return fail(-1, "a periodic boundary that crosses ranks: drive fdtdhip_adjoint_post_stage around the caller's plane transfer");
   for (auto it = p->sources.rbegin(); it != p->sources.rend(); ++it) {
+    if (stage == 0) break;
     const SourceH& s = *it;
     if (s.kind == FDTDHIP_SRC_SOFT_POINT) {
       // the voltage added to E is a constant plus impedance * (loop current of the step
@@ -948,15 +961,13 @@ int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
   }
   size_t first_periodic = p->boundaries.size();
   for (size_t b = 0; b < p->boundaries.size(); ++b)
-    if (p->boundaries[b].kind == 1) {
-      if (p->boundaries[b].idx == FDTDHIP_PERIODIC_X_EXTERNAL)
-        return fail(-1, "the adjoint does not cover a periodic boundary that crosses ranks");
-      if (first_periodic == p->boundaries.size()) first_periodic = b;
-    }
+    if (p->boundaries[b].kind == 1 && first_periodic == p->boundaries.size()) first_periodic = b;
   for (size_t b = p->boundaries.size(); b-- > first_periodic;) {
     const BoundaryRef& br = p->boundaries[b];
+    if (stage >= 0 && (b == ext || (stage == 1) != (b > ext))) continue;
     if (br.kind == 1) {
       const int axis = br.idx;
+      if (axis == FDTDHIP_PERIODIC_X_EXTERNAL) continue;   // (stage < 0 was refused above)
       const int n = axis == 0 ? p->nx : (axis == 1 ? p->ny : p->nz);
       if (n < 2) continue;
       const int64_t total = p->cells() / n * 3;
@@ -973,6 +984,22 @@ int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
                          lamF, mat, k, p->nx, p->ny, p->nz, (T)p->sc, phaseE ? T(1) : T(-1));
     }
   }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
+  if (!p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
+  if (!lamE || !lamH || !work) return fail(-1, "null adjoint array");
+  for (const ObjH& o : p->objs)
+    if (o.kind == FDTDHIP_OBJ_ANISOTROPIC_MODULATED && (!o.modw || !o.etrace || !o.trace))
+      return fail(-1, "the adjoint of a modulated object needs its curl and energy traces");
+  if (int rc = sync_obj_table<T>(p)) return rc;
+  // (with a periodic boundary that crosses ranks the caller has driven the two stages of
+  // the post pieces around its plane transfer: fdtdhip_adjoint_post_stage)
+  if (external_periodic(p) == p->boundaries.size())
+    if (int rc = adjoint_post<T>(p, phaseE, lamE, lamH, -1)) return rc;
   AdjArgs<T> a;
   if (int rc = adjoint_args<T>(p, phaseE, lamE, lamH, work, a)) return rc;
   const dim3 block(256);
@@ -1976,6 +2003,18 @@ int fdtdhip_adjoint_cells(fdtdhip_plan* p, int phase_E, int64_t step, void* lamE
   p->trace_cursor = step;
   const int rc = DISPATCH(p, adjoint_cells<float>(p, phase_E != 0, (float*)lamE, (float*)lamH, (float*)work),
                           adjoint_cells<double>(p, phase_E != 0, (double*)lamE, (double*)lamH, (double*)work));
+  p->trace_cursor = -1;
+  return rc;
+}
+
+int fdtdhip_adjoint_post_stage(fdtdhip_plan* p, int phase_E, int64_t step, int stage, void* lamE,
+                               void* lamH) {
+  if (!p) return fail(-1, "null plan");
+  GUARD(p);
+  if (stage != 0 && stage != 1) return fail(-1, "stage must be 0 or 1");
+  p->trace_cursor = step;
+  const int rc = DISPATCH(p, adjoint_post<float>(p, phase_E != 0, (float*)lamE, (float*)lamH, stage),
+                          adjoint_post<double>(p, phase_E != 0, (double*)lamE, (double*)lamH, stage));
   p->trace_cursor = -1;
   return rc;
 }

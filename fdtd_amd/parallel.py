@@ -327,13 +327,40 @@ class SlabGrid(Grid):
         planes = work.view(self.Nx, self.Ny, self.Nz, 6)
         from_below = bd.zeros((self.Ny, self.Nz, 6)) if r > 0 else None
         from_above = bd.zeros((self.Ny, self.Nz, 6)) if r < p - 1 else None
+        wrap = self._x_wrap
+        wrapped = bd.zeros((self.Ny, self.Nz, 3)) if wrap and r in (0, p - 1) else None
+
+        def undo_wrap(phase, s, lam):
+            """The post pieces of a half step around the transpose of the periodic copy along x
+            (reference fdtd/boundaries.py:173-184: E[0] = E[-1] after the E half step, H[-1] =
+            H[0] after the H half step, first and last plane of the whole simulation): the
+            adjoint of the copied plane is added to the adjoint of the plane it was copied
+            from, on the other end rank, and cleared."""
+            _lib.check(lib.fdtdhip_adjoint_post_stage(plan, phase, s, 1, ptr(lamE), ptr(lamH)))
+            dst_rank, src_rank = (0, p - 1) if phase else (p - 1, 0)      # of the forward copy
+            dst_plane = lam[0] if phase else lam[-1]
+            src_plane = lam[-1] if phase else lam[0]
+            ex = self._start_exchange(dst_plane if r == dst_rank else None, src_rank,
+                                      wrapped if r == src_rank else None, dst_rank)
+            if ex is not None:
+                ex.wait()
+            if r == src_rank:
+                src_plane += wrapped
+            if r == dst_rank:
+                dst_plane.zero_()
+            _lib.check(lib.fdtdhip_adjoint_post_stage(plan, phase, s, 0, ptr(lamE), ptr(lamH)))
+
         for s in range(n - 1, -1, -1):
+            if wrap:
+                undo_wrap(0, s, lamH)
             _lib.check(lib.fdtdhip_adjoint_cells(plan, 0, s, ptr(lamE), ptr(lamH), ptr(work)))
             ex = self._start_exchange(planes[-1] if r < p - 1 else None, r + 1, from_below, r - 1)
             if ex is not None:
                 ex.wait()
             _lib.check(lib.fdtdhip_adjoint_gather(plan, 0, ptr(lamE), ptr(lamH), ptr(work),
                                                   ptr(from_below)))
+            if wrap:
+                undo_wrap(1, s, lamE)
             _lib.check(lib.fdtdhip_adjoint_cells(plan, 1, s, ptr(lamE), ptr(lamH), ptr(work)))
             ex = self._start_exchange(planes[0] if r > 0 else None, r - 1, from_above, r + 1)
             if ex is not None:

@@ -327,6 +327,14 @@ int fdtdhip_adjoint_run_noalloc(fdtdhip_plan* plan, int64_t nsteps, void* lamE, 
  *                            contiguous (ny, nz, 6) block exchanged by the caller between
  *                            the two calls; NULL where the slab ends at a domain edge.
  * A reverse step undoes the H half step first (phase_E = 0), then the E half step.
+ * With FDTDHIP_PERIODIC_X_EXTERNAL in the plan (the copy between the first and the last rank
+ * is the caller's, reference fdtd/boundaries.py:173-184) fdtdhip_adjoint_cells leaves the
+ * post pieces to the caller, who runs, before it and in this order:
+ *   fdtdhip_adjoint_post_stage(stage 1): sources and the boundaries registered after it;
+ *   the transpose of the copy: the adjoint plane of the copy's destination (E half step:
+ *   plane 0 of the first rank; H half step: the last plane of the last rank) is ADDED to
+ *   the adjoint plane of its source on the other rank and then set to zero;
+ *   fdtdhip_adjoint_post_stage(stage 0): the boundaries registered before it.
  * `work` belongs to the two calls of a half step: where the materials are proven constants
  * the library leaves out the entries of cells far from every PML, object and open slab
  * face and derives them inside the gather instead, so the caller may rely on the first and
@@ -335,6 +343,8 @@ int fdtdhip_adjoint_cells(fdtdhip_plan* plan, int phase_E, int64_t step, void* l
                           void* work);
 int fdtdhip_adjoint_gather(fdtdhip_plan* plan, int phase_E, void* lamE, void* lamH, void* work,
                            const void* work_ghost);
+int fdtdhip_adjoint_post_stage(fdtdhip_plan* plan, int phase_E, int64_t step, int stage, void* lamE,
+                               void* lamH);
 
 /* Optional: prove that the material arrays need not be read.  The reference fills
  * inverse_permittivity and inverse_permeability with one value (fdtd/grid.py:135-151)

@@ -410,6 +410,24 @@ ADJOINT_SCENES = {
         steps=30, chunks=(1, 1, 1, 12, 15),
         loss=dict(kind="dense", seed=7),
     ),
+    # a periodic boundary along x between two PMLs in the boundary list: on x-slabs its copy
+    # crosses ranks, and so does its transpose in the reverse sweep
+    "adjoint_xperiodic": dict(
+        grid=dict(shape=(16, 12, 10)),
+        items=[
+            ("pml",       (S(None), S(0, 3), S(None)), {}),
+            ("periodic",  (0, S(None), S(None)), {}),
+            ("pml",       (S(None), S(None), S(-3, None)), {}),      # registered after the periodic one
+            ("pml",       (S(None), S(-2, None), S(None)), {}),
+            ("learnable", (S(5, 12), S(3, 9), S(2, 7)), dict(permittivity=2.6), dict(offdiag_seed=41, offdiag_scale=0.04)),
+            ("learnable", (S(0, 3), S(4, 8), S(1, 5)), dict(permittivity=2.2), dict(offdiag_seed=42, offdiag_scale=0.03)),   # on the low x face
+            ("absorbing", (S(13, 16), S(5, 9), S(3, 6)), dict(permittivity=1.6, conductivity=3e4)),                     # on the high x face
+            ("point",     (1, 6, 4), dict(period=7)),
+            ("point",     (14, 5, 6), dict(period=9, amplitude=0.7)),
+        ],
+        steps=26, chunks=(11, 15),
+        loss=dict(kind="dense", seed=10),
+    ),
     # a voltage source with a series resistance fed back from its own loop current (reference
     # fdtd/sources.py:708-737 with fdtd/detectors.py:443-464 on the tape), next to a learnable
     # object; two runs, so that the first step of the second one takes its current from the
