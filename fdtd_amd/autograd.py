@@ -26,7 +26,7 @@ operation: fdtd/grid.py:275-325 under fdtd/backend.py:57-59); its backward is th
 of that half step alone (``fdtdhip_adjoint_cells`` + ``fdtdhip_adjoint_gather``).
 
 On x-slabs (``fdtd_amd.parallel.SlabGrid``) every rank records the same chain of
-nodes for its planes; the reverse sweep exchanges one plane of difference adjoints
+nodes for its planes (whole runs or hand-driven half steps); the reverse sweep exchanges one plane of difference adjoints
 with a neighbour per half step, so ``backward`` is a collective: every rank must
 reach it (``SlabGrid.backward(loss)`` makes sure of that).
 """
@@ -175,13 +175,7 @@ class _Run(torch.autograd.Function):
                                                             _ptr(gm)))
             gmods.append(gm)
         try:
-            if ctx.half is None:
-                grid._native_adjoint(lib, n, lamE, lamH, work)
-            else:
-                # the adjoint of that half step alone: per-cell pass, then the gather
-                phase = 1 if ctx.half == "E" else 0
-                _lib.check(lib.fdtdhip_adjoint_cells(plan, phase, 0, _ptr(lamE), _ptr(lamH), _ptr(work)))
-                _lib.check(lib.fdtdhip_adjoint_gather(plan, phase, _ptr(lamE), _ptr(lamH), _ptr(work), None))
+            grid._native_adjoint(lib, n, lamE, lamH, work, ctx.half)
         finally:
             for o in objs:
                 _lib.check(lib.fdtdhip_plan_set_object_trace(plan, o._native_id, None, 0))

@@ -468,15 +468,6 @@ class Grid:
         autograd.differentiable_half_step(self, phase_E)
         return True
 
-    def _no_half_step_autograd(self):
-        """x-slabs record whole steps only (their reverse sweep is driven per step)."""
-        from . import autograd
-
-        if not bd.staging and autograd.needs_grad(self):
-            raise NotImplementedError(
-                "on x-slabs gradients are recorded per full step: call grid.step() / grid.run(n) "
-                "(or wrap the half steps in torch.no_grad())")
-
     def step(self):
         """One full step: E half step, H half step (reference fdtd/grid.py:267-273)."""
         self._advance(1)
@@ -520,10 +511,16 @@ class Grid:
             if finish is not None:
                 finish(n)
 
-    def _native_adjoint(self, lib, n, lamE, lamH, work):
-        """Reverse sweep over the last ``n`` steps (see ``fdtd_amd/autograd.py``)."""
+    def _native_adjoint(self, lib, n, lamE, lamH, work, half=None):
+        """Reverse sweep over the last ``n`` steps, or (``half`` = "E" / "H") the adjoint of
+        that one half step alone: per-cell pass, then the gather (see ``fdtd_amd/autograd.py``)."""
         p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        _lib.check(lib.fdtdhip_adjoint_run(self._plan, n, p(lamE), p(lamH), p(work)))
+        if half is None:
+            _lib.check(lib.fdtdhip_adjoint_run(self._plan, n, p(lamE), p(lamH), p(work)))
+            return
+        phase = 1 if half == "E" else 0
+        _lib.check(lib.fdtdhip_adjoint_cells(self._plan, phase, 0, p(lamE), p(lamH), p(work)))
+        _lib.check(lib.fdtdhip_adjoint_gather(self._plan, phase, p(lamE), p(lamH), p(work), None))
 
     def _provide_step_buffers(self):
         """Second E/H (and PML psi_E) buffers that let ``run`` use the fused full-step

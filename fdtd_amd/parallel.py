@@ -256,21 +256,35 @@ class SlabGrid(Grid):
             eng.read_deferred_currents()
 
     def update_E(self):
-        self._no_half_step_autograd()
-        eng = self._engine
-        eng.prepare()
-        eng.reserve_detectors(1, 0)
-        self._half_step_E(eng, self.time_steps_passed)
-        eng.commit_detectors(1, 0)
-        self._finish_sources(1)
+        if not self._half_step_recorded(True):
+            self._native_half_step(None, True)
 
     def update_H(self):
-        self._no_half_step_autograd()
+        if not self._half_step_recorded(False):
+            self._native_half_step(None, False)
+
+    def _native_half_step(self, lib, phase_E):
         eng = self._engine
         eng.prepare()
-        eng.reserve_detectors(0, 1)
-        self._half_step_H(eng, self.time_steps_passed)
-        eng.commit_detectors(0, 1)
+        if phase_E:
+            eng.reserve_detectors(1, 0)
+            self._half_step_E(eng, self.time_steps_passed)
+            eng.commit_detectors(1, 0)
+            self._finish_sources(1)
+        else:
+            eng.reserve_detectors(0, 1)
+            self._half_step_H(eng, self.time_steps_passed)
+            eng.commit_detectors(0, 1)
+
+    def _half_step_recorded(self, phase_E):
+        """As on an undivided grid, and collective like ``_advance``: either every rank records
+        the half step or none does."""
+        from . import autograd
+
+        if bd.staging or not self._any_rank_needs_grad():
+            return False
+        autograd.differentiable_half_step(self, phase_E)
+        return True
 
     def _advance(self, n):
         if n <= 0:
@@ -315,7 +329,7 @@ class SlabGrid(Grid):
         self._finish_sources(n)
 
     # ----------------------------------------------------------------- adjoint
-    def _native_adjoint(self, lib, n, lamE, lamH, work):
+    def _native_adjoint(self, lib, n, lamE, lamH, work, half=None):
         """Reverse sweep on a slab.  The forward x differences across a slab face read the
         neighbour's plane, so their adjoints flow back across it: undoing the H half step,
         plane 0 gathers from the LAST plane of difference adjoints of the rank below;
@@ -350,7 +364,7 @@ class SlabGrid(Grid):
                 dst_plane.zero_()
             _lib.check(lib.fdtdhip_adjoint_post_stage(plan, phase, s, 0, ptr(lamE), ptr(lamH)))
 
-        for s in range(n - 1, -1, -1):
+        def undo_H(s):
             if wrap:
                 undo_wrap(0, s, lamH)
             _lib.check(lib.fdtdhip_adjoint_cells(plan, 0, s, ptr(lamE), ptr(lamH), ptr(work)))
@@ -359,6 +373,8 @@ class SlabGrid(Grid):
                 ex.wait()
             _lib.check(lib.fdtdhip_adjoint_gather(plan, 0, ptr(lamE), ptr(lamH), ptr(work),
                                                   ptr(from_below)))
+
+        def undo_E(s):
             if wrap:
                 undo_wrap(1, s, lamE)
             _lib.check(lib.fdtdhip_adjoint_cells(plan, 1, s, ptr(lamE), ptr(lamH), ptr(work)))
@@ -367,6 +383,13 @@ class SlabGrid(Grid):
                 ex.wait()
             _lib.check(lib.fdtdhip_adjoint_gather(plan, 1, ptr(lamE), ptr(lamH), ptr(work),
                                                   ptr(from_above)))
+
+        if half is not None:      # the adjoint of one hand-driven half step
+            (undo_E if half == "E" else undo_H)(0)
+            return
+        for s in range(n - 1, -1, -1):
+            undo_H(s)
+            undo_E(s)
 
     def backward(self, loss):
         """Back-propagate this rank's part of the loss (the total loss is the sum over
