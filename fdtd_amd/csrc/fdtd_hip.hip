@@ -23,6 +23,7 @@
 #include "yee_adjoint.hpp"
 #include "yee_step.hpp"
 #include "yee_march.hpp"
+#include "yee_shell.hpp"
 
 namespace {
 
@@ -1158,6 +1159,34 @@ constexpr int64_t FUSED_AUTO_MAX_CELLS = 1 << 17;
 //   FUSED_MARCH : step_march, workgroups marching along x -- wins on large 3-D grids, where
 //                 it moves 12 instead of 18 values per cell and step.
 enum FusedKind { FUSED_NONE = 0, FUSED_CELL, FUSED_MARCH };
+constexpr int64_t MARCH_SHELL_SHARE = 6;   // shell cells at most a sixth of the grid
+
+// Plans with PML faces take the marching step over the box no face reaches, with half steps
+// of their own for the shell around it (yee_shell.hpp).  That needs a box.
+// `hole`: the box that holds every object, clipped to the core (empty without objects): its E
+// half step belongs to the shell as well.
+bool march_core(const fdtdhip_plan* p, int (&core)[6], int (&hole)[6]) {
+  BulkArgs<float> b;
+  fill_core<float>(p, b);
+  for (int n = 0; n < 6; ++n) core[n] = b.core[n];
+  for (int ax = 0; ax < 3; ++ax) {
+    if (core[2 * ax + 1] - core[2 * ax] < 1) return false;
+    hole[2 * ax] = std::min(std::max(b.hull[2 * ax], core[2 * ax]), core[2 * ax + 1]);
+    hole[2 * ax + 1] = std::min(std::max(b.hull[2 * ax + 1], hole[2 * ax]), core[2 * ax + 1]);
+  }
+  if (p->objs.empty() || hole[1] == hole[0] || hole[3] == hole[2] || hole[5] == hole[4])
+    for (int n = 0; n < 6; ++n) hole[n] = 0;
+  return true;
+}
+
+// Whether the marching kernel itself evaluates the E half step of the cell of element `elem`.
+bool march_owns(const fdtdhip_plan* p, const int (&core)[6], const int (&hole)[6], int64_t elem) {
+  const int64_t plane = (int64_t)p->ny * p->nz, cell = elem / 3;
+  const int i = (int)(cell / plane), j = (int)((cell % plane) / p->nz), k = (int)(cell % p->nz);
+  if (i < core[0] || i >= core[1] || j < core[2] || j >= core[3] || k < core[4] || k >= core[5])
+    return false;
+  return !(i >= hole[0] && i < hole[1] && j >= hole[2] && j < hole[3] && k >= hole[4] && k < hole[5]);
+}
 
 FusedKind fused_kind(const fdtdhip_plan* p) {
   // FDTDHIP_FUSED=0 never, =1 step_fused whenever possible, =2 step_march whenever possible
@@ -1189,15 +1218,21 @@ FusedKind fused_kind(const fdtdhip_plan* p) {
   if (points > MAX_STEP_SOURCES) return FUSED_NONE;
   const bool cell_ok = p->nx <= 65535 && (int64_t)p->ny * p->nz < (1ll << 30) &&
                        p->cells() * 3 < (1ll << 31);   // the kernel's element offsets are 32-bit
-  const bool march_ok = p->pmls.empty() && p->nz <= 64 * MARCH_MAX_WAVES && p->nx / 16 <= 65535;
+  int core[6], hole[6] = {0, 0, 0, 0, 0, 0};
+  const bool march_ok = ((p->pmls.empty() && p->objs.empty()) || march_core(p, core, hole)) &&
+                        p->nz <= 64 * MARCH_MAX_WAVES && p->nx / 16 <= 65535;
+  // the cells that take half steps of their own next to the marching kernel
+  const int64_t shell_cells = p->pmls.empty() && p->objs.empty() ? 0 :
+      p->cells() - (int64_t)(core[1] - core[0]) * (core[3] - core[2]) * (core[5] - core[4]) +
+      (int64_t)(hole[1] - hole[0]) * (hole[3] - hole[2]) * (hole[5] - hole[4]);
   if (mode == 1) return cell_ok ? FUSED_CELL : FUSED_NONE;
   if (mode == 2) return march_ok ? FUSED_MARCH : FUSED_NONE;
   const int thin = std::min(p->nx, std::min(p->ny, p->nz));
   if (cell_ok && p->cells() <= FUSED_AUTO_MAX_CELLS && thin == 1) return FUSED_CELL;
-  // (with objects the kernel needs 130 registers -- one workgroup of eight waves per CU -- and
-  // its loads wait for one another: 512^3 float32, two 64^3 boxes: 2.08 against 1.63 ms)
-  if (march_ok && p->objs.empty() && p->nz >= 128 && p->ny >= 64 && p->nx >= 64 &&
-      p->cells() >= (1ll << 22))
+  // (PML faces and objects: the shell and the box of the objects take half steps of their
+  // own at a third of the marching kernel's rate per cell -- worth it while they are few)
+  if (march_ok && p->nz >= 128 && p->ny >= 64 && p->nx >= 64 && p->cells() >= (1ll << 22) &&
+      shell_cells * MARCH_SHELL_SHARE <= p->cells())
     return FUSED_MARCH;
   return FUSED_NONE;
 }
@@ -1283,6 +1318,88 @@ int launch_march(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
   return 0;
 }
 
+// The marching step of a plan with PML faces and/or objects: E half step of the shell, the
+// marching kernel over the core, H half step of the shell (yee_shell.hpp).
+template <typename T>
+int launch_march_shell(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
+  constexpr int TY = sizeof(T) == 4 ? 4 : 2;
+  int c[6], hole[6];
+  if (!march_core(p, c, hole)) return fail(-1, "internal: no core box for the marching step");
+  const int nx = p->nx, ny = p->ny, nz = p->nz;
+  // the shell as disjoint boxes: x slabs over everything, y slabs between them, z slabs
+  // inside; and the box of the objects, for the E half step only
+  const ShellBox boxes[MAX_SHELL_BOXES] = {
+      {0, c[0], 0, ny, 0, nz},           {c[1], nx, 0, ny, 0, nz},
+      {c[0], c[1], 0, c[2], 0, nz},      {c[0], c[1], c[3], ny, 0, nz},
+      {c[0], c[1], c[2], c[3], 0, c[4]}, {c[0], c[1], c[2], c[3], c[5], nz},
+      {hole[0], hole[1], hole[2], hole[3], hole[4], hole[5]}};
+  auto table = [&](int nboxes) {
+    Shell sh;
+    sh.count = 0;
+    sh.first[0] = 0;
+    for (int nb = 0; nb < nboxes; ++nb) {
+      const ShellBox& b = boxes[nb];
+      const int64_t n = (int64_t)std::max(b.i1 - b.i0, 0) * std::max(b.j1 - b.j0, 0) * std::max(b.k1 - b.k0, 0);
+      if (n == 0) continue;
+      sh.box[sh.count] = b;
+      sh.first[sh.count + 1] = sh.first[sh.count] + blocks_for(n);
+      ++sh.count;
+    }
+    for (int n = sh.count; n < MAX_SHELL_BOXES; ++n) {
+      sh.box[n] = ShellBox{0, 0, 0, 0, 0, 0};
+      sh.first[n + 1] = sh.first[sh.count];
+    }
+    return sh;
+  };
+  const Shell shE = table(MAX_SHELL_BOXES), shH = table(MAX_SHELL_BOXES - 1);
+  const bool pml = !p->pmls.empty();
+  if (shE.count) {
+    const dim3 grid((unsigned)shE.first[shE.count]), block(256);
+    if (pml && obj) hipLaunchKernelGGL((shell_E<T, true, true>), grid, block, 0, p->stream, a.e, a.E1, shE);
+    else if (pml) hipLaunchKernelGGL((shell_E<T, true, false>), grid, block, 0, p->stream, a.e, a.E1, shE);
+    else hipLaunchKernelGGL((shell_E<T, false, true>), grid, block, 0, p->stream, a.e, a.E1, shE);
+  }
+  // source points: the marching kernel adds those on cells whose E half step it evaluates,
+  // the others are added to the shell's new E here
+  MarchArgs<T> m;
+  m.s = a;
+  ShellSources<T> ss;
+  ss.n = m.s.nsrc = 0;
+  for (int n = 0; n < a.nsrc; ++n) {
+    if (march_owns(p, c, hole, a.src_elem[n])) {
+      m.s.src_elem[m.s.nsrc] = a.src_elem[n];
+      m.s.src_value[m.s.nsrc++] = a.src_value[n];
+    } else {
+      ss.elem[ss.n] = a.src_elem[n];
+      ss.value[ss.n++] = a.src_value[n];
+    }
+  }
+  if (ss.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, a.E1, ss);
+  for (int n = 0; n < 6; ++n) { m.box[n] = c[n]; m.hole[n] = hole[n]; }
+  const bool holed = hole[1] > hole[0];
+  const int tiles = (c[3] - c[2] + TY - 1) / TY, planes = c[1] - c[0];
+  // chunks of planes: as many as give two rounds of two workgroups per CU, not a few more
+  const int chunks = std::max(1, 1024 / tiles);
+  const int lx = m.lx = std::min(128, std::max(16, (planes + chunks - 1) / chunks));
+  const int waves = (nz + 63) / 64;
+  m.band = tiles >= 16 ? (tiles + 7) / 8 : 0;
+  const dim3 grid(m.band ? 8 * m.band : tiles, (planes + lx - 1) / lx, 1), block(64 * waves);
+  const bool constants = p->mat_const[0] && p->mat_const[1];
+#define MARCH(MW)                                                                                     \
+  if (holed && constants) hipLaunchKernelGGL((step_march_box<T, TY, true, true, MW>), grid, block, 0, p->stream, m); \
+  else if (holed) hipLaunchKernelGGL((step_march_box<T, TY, true, false, MW>), grid, block, 0, p->stream, m); \
+  else if (constants) hipLaunchKernelGGL((step_march_box<T, TY, false, true, MW>), grid, block, 0, p->stream, m); \
+  else hipLaunchKernelGGL((step_march_box<T, TY, false, false, MW>), grid, block, 0, p->stream, m);
+  if (waves <= 8) { MARCH(8) } else { MARCH(MARCH_MAX_WAVES) }
+#undef MARCH
+  if (shH.count) {
+    BulkArgs<T> h = a.h;
+    h.G = a.E1;     // the H half step is driven by the new E
+    hipLaunchKernelGGL((shell_H<T, true>), dim3((unsigned)shH.first[shH.count]), dim3(256), 0, p->stream, h, a.H1, shH);
+  }
+  return 0;
+}
+
 template <typename T>
 int fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {
   if (int rc = sync_obj_table<T>(p)) return rc;
@@ -1324,7 +1441,8 @@ int fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {
   }
   if (int rc = sync_pml_tables<T>(p)) return rc;
   // p->step_flipped: the state currently lives in the second buffers
-  a.e.pml = pml_table<T>(p, p->step_flipped ? TAB_E_BA : TAB_E_AB);
+  // (the marching step advances the memory variables in place: its shell cells are evaluated once)
+  a.e.pml = pml_table<T>(p, march ? TAB_E : (p->step_flipped ? TAB_E_BA : TAB_E_AB));
   a.h.pml = pml_table<T>(p, TAB_H);
   a.E1 = (T*)p->E_alt;
   a.H1 = (T*)p->H_alt;
@@ -1354,7 +1472,7 @@ int fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {
     HIPCHK(hipEventRecord(p->ev_pool[slot].first, p->stream));
   }
   if (march) {
-    if (int rc = launch_march<T>(p, a, obj)) return rc;
+    if (int rc = pml || obj ? launch_march_shell<T>(p, a, obj) : launch_march<T>(p, a, obj)) return rc;
   } else if (pml && obj) hipLaunchKernelGGL((step_fused<T, true, true>), grid, block, 0, p->stream, a);
   else if (pml) hipLaunchKernelGGL((step_fused<T, true, false>), grid, block, 0, p->stream, a);
   else if (obj) hipLaunchKernelGGL((step_fused<T, false, true>), grid, block, 0, p->stream, a);

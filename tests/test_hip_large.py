@@ -326,11 +326,19 @@ def test_long_run_against_oracle(dtype):
 
 _MARCH_CASES = [("float32", (100, 170, 250)), ("float32", (96, 128, 1024)), ("float64", (99, 170, 260))]
 _MARCH_IDS = ["f32-ragged", "f32-1024-cell-rows", "f64-ragged"]
+# PML faces of the marching-kernel tests as (axis, side, thickness), in registration order
+_MARCH_FACES = {
+    "no-pml": [],
+    # the order DomainBorderPML registers them in, corners shared by three faces
+    "six-faces": [(2, "low", 7), (2, "high", 7), (0, "low", 7), (0, "high", 7), (1, "low", 7), (1, "high", 7)],
+    # another order of the axes, unequal thicknesses, faces missing, one a single cell thick
+    "four-faces": [(1, "high", 5), (0, "low", 9), (2, "low", 1), (2, "high", 11)],
+}
 
 
 @pytest.mark.parametrize("dtype,shape", _MARCH_CASES, ids=_MARCH_IDS)
 def test_whole_step_marching_kernel_equals_half_steps_bitwise(dtype, shape):
-    """Large 3-D grids without PMLs and objects take whole steps in one launch (workgroups
+    """Large 3-D grids take whole steps with one pass over memory (workgroups
     marching along x, out of place).  The same scene advanced by `run` (marching kernel, an odd
     number of steps so that a last step of two half-step launches follows the pairs) and by
     explicit half steps must give identical bits: fields, detector records; and both must
@@ -340,10 +348,13 @@ def test_whole_step_marching_kernel_equals_half_steps_bitwise(dtype, shape):
     _march_case(dtype, shape, objects=False)
 
 
-def test_whole_step_marching_kernel_with_objects_forced():
-    """The marching kernel's object variant (objects of every kind) is not what the library
-    picks by default -- two half-step launches are faster there -- but FDTDHIP_FUSED=2 applies
-    it: same bitwise checks as above.  The switch is read once per process, hence the child."""
+def test_whole_step_marching_kernel_with_faces_and_objects_forced():
+    """With PML faces and / or objects the marching kernel covers the box no face reaches,
+    minus the E half step of the box that holds the objects; the shell around it and that
+    box take out-of-place half steps of their own.  The library picks this while the shell
+    is a small part of the grid (the 512^3 tests run it that way); FDTDHIP_FUSED=2 applies it
+    to the smaller grids here: same bitwise checks as above, the PML memory variables
+    included.  The switch is read once per process, hence the child."""
     import os
     import subprocess
     import sys
@@ -352,15 +363,17 @@ def test_whole_step_marching_kernel_with_objects_forced():
     code = (f"import sys\nsys.path[:0] = [{os.path.dirname(here)!r}, {here!r}]\n"
             "import test_hip_large as t\n"
             "for dtype, shape in t._MARCH_CASES:\n"
-            "    t._march_case(dtype, shape, objects=True)\n"
-            "print('marched with objects')\n")
+            "    for faces, objects in (('six-faces', False), ('four-faces', False), ('no-pml', True),\n"
+            "                           ('six-faces', True), ('four-faces', True)):\n"
+            "        t._march_case(dtype, shape, objects=objects, faces=faces)\n"
+            "print('marched with faces and objects')\n")
     done = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FDTDHIP_FUSED="2"),
                           capture_output=True, text=True, timeout=280, cwd=here)
     assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
-    assert "marched with objects" in done.stdout
+    assert "marched with faces and objects" in done.stdout
 
 
-def _march_case(dtype, shape, objects):
+def _march_case(dtype, shape, objects, faces="no-pml"):
     fdtd.set_backend(f"hip.{dtype}")
     nx, ny, nz = shape
     rs = np.random.RandomState(21)
@@ -368,6 +381,9 @@ def _march_case(dtype, shape, objects):
     dense = nz == 1024
     ie = 1.0 / (1 + rs.rand(*shape, 3)) if dense else None
     steps = 7
+    # (sources on the corners of the grid -- inside the faces, if any -- and under objects too)
+    sources = (((nx // 2, ny // 2, nz // 2), 11), ((0, 0, 0), 7), ((nx - 1, ny - 1, nz - 1), 9),
+               ((33, 64, 63), 13), ((33, 64, 64), 5))
 
     def build():
         g = fdtd.Grid(shape)
@@ -382,8 +398,12 @@ def _march_case(dtype, shape, objects):
             with torch.no_grad():
                 ani.inverse_permittivity += fdtd.backend.array(off)
             g[40:60, 70:120, 30:80] = fdtd.AbsorbingObject(permittivity=1.5, conductivity=3e-3)
-        for cell, period in (((nx // 2, ny // 2, nz // 2), 11), ((0, 0, 0), 7), ((nx - 1, ny - 1, nz - 1), 9),
-                             ((33, 64, 63), 13), ((33, 64, 64), 5)):
+            g[2:12, ny - 30:ny - 2, 20:60] = fdtd.Object(permittivity=2.5)   # reaches into faces
+        for axis, side, t in _MARCH_FACES[faces]:
+            loc = [slice(None)] * 3
+            loc[axis] = slice(0, t) if side == "low" else slice(-t, None)
+            g[tuple(loc)] = fdtd.PML()
+        for cell, period in sources:
             g[cell] = fdtd.PointSource(period=period)
         det = fdtd.LineDetector()
         g[5:65, 64, 64] = det
@@ -412,6 +432,10 @@ def _march_case(dtype, shape, objects):
     assert torch.equal(a.E, b.E) and torch.equal(a.H, b.H)
     assert torch.equal(torch.stack(list(da.E)), torch.stack(list(db.E)))
     assert torch.equal(torch.stack(list(da.H)), torch.stack(list(db.H)))
+    for pa, pb in zip(a.boundaries, b.boundaries):
+        assert torch.equal(pa._psiE, pb._psiE) and torch.equal(pa._psiH, pb._psiH)
+        if pa.thickness > 1:   # (a face one cell thick never takes a field difference)
+            assert float(pa._psiE.abs().max()) > 0 and float(pa._psiH.abs().max()) > 0
     if nz == 1024:
         return      # (the oracle comparison of the other two shapes covers the arithmetic)
     o = orc.OracleGrid(shape)
@@ -421,8 +445,10 @@ def _march_case(dtype, shape, objects):
         oa = o.add_object((25, 50, 20, 60, 100, 190), 1.8, kind="anisotropic")
         oa.inverse_permittivity += off
         o.add_object((40, 60, 70, 120, 30, 80), 1.5, kind="absorbing", conductivity=3e-3)
-    for cell, period in (((nx // 2, ny // 2, nz // 2), 11), ((0, 0, 0), 7), ((nx - 1, ny - 1, nz - 1), 9),
-                         ((33, 64, 63), 13), ((33, 64, 64), 5)):
+        o.add_object((2, 12, ny - 30, ny - 2, 20, 60), 2.5)
+    for axis, side, t in _MARCH_FACES[faces]:
+        o.add_pml(axis, side, t)
+    for cell, period in sources:
         o.add_point_source(cell, period=period)
     o.run(steps)
     assert rel_l2(host(a.E), o.E) <= TOL[dtype] and rel_l2(host(a.H), o.H) <= TOL[dtype]
