@@ -148,22 +148,29 @@ def torch_no_grad():
 
 
 def timed_run(grid, lib, _lib, steps, sync, events=True):
-    """Time `steps` steps; returns (seconds, ms in E kernels, launches, ms in H kernels, launches).
-    events=False leaves out the HIP events around every bulk launch (they cost a launch-bound
+    """Time `steps` steps; returns (seconds, timing) with timing = {"ms": [H bulk, E bulk,
+    whole-step kernels, shell launches], "n": launches of each, "whole_steps": steps advanced
+    by a whole-step kernel, "core" / "hole": the boxes that kernel covers}.
+    events=False leaves out the HIP events around every launch (they cost a launch-bound
     step several microseconds); the kernel times are then zero."""
     plan = grid._plan
     _lib.check(lib.fdtdhip_plan_enable_timing(plan, 1 if events else 0))
+    taken0 = getattr(grid, "whole_steps_taken", None)
     sync()
     t0 = time.perf_counter()
     with torch_no_grad():     # plain time stepping: nothing to record, no collective about it
         grid.run(steps, progress_bar=False)
     sync()
     elapsed = time.perf_counter() - t0
-    msE, nE, msH, nH = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
-    _lib.check(lib.fdtdhip_plan_get_timing(plan, ctypes.byref(msE), ctypes.byref(nE),
-                                            ctypes.byref(msH), ctypes.byref(nH)))
+    ms, n = (ctypes.c_double * 4)(), (ctypes.c_int64 * 4)()
+    _lib.check(lib.fdtdhip_plan_get_timing_parts(plan, ms, n))
     _lib.check(lib.fdtdhip_plan_enable_timing(plan, 0))
-    return elapsed, msE.value, nE.value, msH.value, nH.value
+    core, hole = (ctypes.c_int32 * 6)(), (ctypes.c_int32 * 6)()
+    staged = 1 if taken0 is not None and grid._world > 1 else 0
+    _lib.check(lib.fdtdhip_plan_whole_step_kind(plan, staged, core, hole))
+    whole = n[2] if taken0 is None or grid._world == 1 else grid.whole_steps_taken - taken0
+    return elapsed, {"ms": list(ms), "n": list(n), "whole_steps": int(whole),
+                     "core": list(core), "hole": list(hole)}
 
 
 def use_material_arrays(grid, lib, _lib):
@@ -173,48 +180,69 @@ def use_material_arrays(grid, lib, _lib):
     _lib.check(lib.fdtdhip_plan_scan_materials(grid._plan, 0))
 
 
-def roofline(grid, cells, es, ms_e, ms_h, mask, steps, workload, launches_e=None, launches_h=None):
+def roofline(grid, cells, es, timing, mask, steps, workload):
     """The dominant kernel is the bulk half-step kernel, or -- where the library takes whole
-    steps in one pass (plans without PMLs on large 3-D grids; the README example) -- the
-    whole-step kernel, whose launches the library's timer counts with the E launches.  One
-    half step of one GPU = `cells` cells = one bulk launch on a single GPU; on a slab it is
-    two launches (interior planes, then the plane that waits for the halo), so durations are
-    summed per half step before dividing.  The whole-step kernel's algorithmic bytes are both
-    fields read and written once (12 values per cell, plus the material arrays where they are
-    read).  A run of an odd number of steps ends with one step of two half-step launches; the
-    bytes of every launch are then added up and divided by the total kernel time."""
+    steps in one pass (large 3-D grids; the README example) -- the whole-step kernel.
+
+    Half steps: one half step of one GPU = `cells` cells = one bulk launch on a single GPU;
+    on a slab it is two launches (interior planes, then the plane that waits for the halo),
+    so durations are summed per half step before dividing.  Algorithmic bytes: the advanced
+    field read and written, the driving field read, the material array unless it is a
+    constant, the two memory variables of every PML cell read and written.
+
+    Whole steps: the marching kernel advances E and H of its box (`core`: the whole grid, or
+    the cells no PML reaches and no open slab face touches) in one launch per step (two on
+    an x-slab, around the plane exchanges; summed per step).  Its algorithmic bytes are E
+    and H read once and written once, 12 values per cell (9 in the box of the objects, whose
+    E half step is the shell launches'), plus the material arrays where they are read.  The
+    half-step launches over the shell (PML cells, objects, slab faces) are reported next to
+    it as `shell_ms_per_step`; a run of an odd number of steps ends with one step of two
+    half-step launches, reported as `half_step_launches`."""
+    ms, n, whole = timing["ms"], timing["n"], timing["whole_steps"]
     be, bh = half_step_bytes(grid, cells, es, mask)
-    whole = 0 if launches_e is None else max(0, launches_e - launches_h)   # whole-step launches
-    whole_bytes = be + bh - 6 * cells * es      # E and H are read once instead of twice
-    if whole:
-        halves = steps - whole                  # steps taken as two half-step launches
-        avg_ms = (ms_e + ms_h) / (whole + 2 * halves)
-        per_launch = (whole * whole_bytes + halves * (be + bh)) / (whole + 2 * halves)
+    mat = {0: "arrays", 1: "inverse permittivity constant", 2: "inverse permeability constant",
+           3: "constants"}[mask]
+    roof = {"bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 0.0,
+            "traffic": None, "traffic_source": None}
+    if whole > 0:
+        c, h = timing["core"], timing["hole"]
+        core = (c[1] - c[0]) * (c[3] - c[2]) * (c[5] - c[4])
+        hole = (h[1] - h[0]) * (h[3] - h[2]) * (h[5] - h[4])
+        values = 12 * core - 3 * hole
+        if not mask & 1:
+            values += 3 * (core - hole)
+        if not mask & 2:
+            values += 3 * core
+        per_launch = values * es
+        avg_ms = ms[2] / whole
+        roof.update({
+            "kernel": ("one-lane-per-cell whole-step kernel" if workload == "c1" else
+                       "marching whole-step kernel (E and H in one pass)" if core == cells else
+                       "marching whole-step kernel over the cells away from PMLs, objects and slab "
+                       "faces; half-step launches over the others"),
+            "kernel_cells": core, "grid_cells": cells,
+            "launches_per_step": round(n[2] / whole, 2),
+            "shell_ms_per_step": round(ms[3] / whole, 4),
+            "half_step_launches": n[0] + n[1],
+            # the same duration priced at 24 values per cell and step whatever the materials
+            # are (every array counted as read): an effective rate, not HBM traffic
+            "all_arrays_equivalent_GBps": round(core * 24 * es / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
+        })
     else:
-        avg_ms = (ms_e + ms_h) / (2 * steps)
+        avg_ms = (ms[0] + ms[1]) / (2 * steps)
         per_launch = (be + bh) / 2
-    whole_step = whole > 0
+        roof.update({
+            "kernel": "bulk half-step kernel (E and H)",
+            "all_arrays_equivalent_GBps": round(cells * 12 * es / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
+            "avg_launch_ms_E": round(ms[1] / steps, 4),
+            "avg_launch_ms_H": round(ms[0] / steps, 4),
+        })
     achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    roof = {
-        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
-        "kernel": ("one-lane-per-cell whole-step kernel" if workload == "c1"
-                   else "marching whole-step kernel (E and H in one pass)") if whole_step
-                  else "bulk half-step kernel (E and H)",
-        "materials": {0: "arrays", 1: "inverse permittivity constant", 2: "inverse permeability constant",
-                      3: "constants"}[mask],
-        "bytes_per_launch": per_launch,
-        # the same duration priced at 12 values per cell and half step whatever the
-        # materials are (every array counted as read): an effective rate, not HBM traffic
-        "all_arrays_equivalent_GBps": round(cells * (24 if whole_step else 12) * es / (avg_ms * 1e-3) / 1e9, 1)
-                                      if avg_ms > 0 else 0.0,
-        "avg_launch_ms": round(avg_ms, 4),
-        "avg_launch_ms_E": round(ms_e / steps, 4),     # (whole-step launches are counted here)
-        "avg_launch_ms_H": round(ms_h / steps, 4),
-    }
+    roof.update({"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                 "materials": mat, "bytes_per_launch": per_launch, "avg_launch_ms": round(avg_ms, 4)})
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
-        key = f"{workload}:{roof['materials']}" + (":whole-step" if whole_step else "")
+        key = f"{workload}:{mat}" + (":whole-step" if whole > 0 else "")
         rec = json.load(open(pmc)).get(key)
         if rec:
             roof["traffic"] = rec.get("bytes_per_launch")
@@ -237,8 +265,8 @@ def measure_single(workload, steps, warmup, materials="auto"):
         grid.run(warmup, progress_bar=False)
     torch.cuda.synchronize()
     mask = 0 if materials == "arrays" else _lib.check(lib.fdtdhip_plan_scan_materials(grid._plan, 1))
-    elapsed, msE, nE, msH, nH = timed_run(grid, lib, _lib, steps, torch.cuda.synchronize)
-    roof = roofline(grid, cells, es, msE, msH, mask, steps, workload, nE, nH)
+    elapsed, timing = timed_run(grid, lib, _lib, steps, torch.cuda.synchronize)
+    roof = roofline(grid, cells, es, timing, mask, steps, workload)
     rec = {
         "workload": desc, "name": workload, "dtype": dt, "steps": steps, "warmup": warmup,
         "value": round(cells * steps / elapsed / 1e9, 3), "unit": "Gcells/s",
@@ -246,6 +274,7 @@ def measure_single(workload, steps, warmup, materials="auto"):
         "avg_launch_ms": roof["avg_launch_ms"], "achieved": roof["achieved"], "frac": roof["frac"],
         "materials": roof["materials"], "kernel": roof["kernel"],
         "bytes_per_launch": roof["bytes_per_launch"], "traffic": roof["traffic"],
+        **{k: roof[k] for k in ("kernel_cells", "shell_ms_per_step", "half_step_launches") if k in roof},
     }
     del grid
     torch.cuda.empty_cache()
@@ -422,17 +451,16 @@ def main():
         # launch-bound: the step rate is timed without per-launch events, the kernel
         # durations come from a second pass of the same steps with them
         elapsed = timed_run(grid, lib, _lib, args.steps, sync, events=False)[0]
-        _, msE, nE, msH, nH = timed_run(grid, lib, _lib, args.steps, sync)
+        _, timing = timed_run(grid, lib, _lib, args.steps, sync)
     else:
-        elapsed, msE, nE, msH, nH = timed_run(grid, lib, _lib, args.steps, sync)
+        elapsed, timing = timed_run(grid, lib, _lib, args.steps, sync)
     elapsed = max_over_ranks(elapsed)
 
     out = None
     if rank == 0:
         value = cells * world * args.steps / elapsed / 1e9
-        roof = roofline(grid, cells, es, msE, msH, mask, args.steps, workload,
-                        nE if world == 1 else None, nH)
-        roof["launches"] = nE + nH
+        roof = roofline(grid, cells, es, timing, mask, args.steps, workload)
+        roof["launches"] = sum(timing["n"])
         out = {
             "metric": "Yee cell-updates/s", "value": round(value, 3), "unit": "Gcells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -59,6 +59,8 @@ PROTOTYPES = {
     "fdtdhip_update_E_post_stage": (_i, [_p, _i64, _i]),
     "fdtdhip_update_H_post_stage": (_i, [_p, _i64, _i]),
     "fdtdhip_run": (_i, [_p, _i64, _i64]),
+    "fdtdhip_plan_whole_step_kind": (_i, [_p, _i, _pi32, _pi32]),
+    "fdtdhip_step_stage": (_i, [_p, _i64, _i]),
     "fdtdhip_plan_set_object_trace": (_i, [_p, _i, _p, _i64]),
     "fdtdhip_plan_set_object_grad": (_i, [_p, _i, _p]),
     "fdtdhip_plan_set_object_modifier": (_i, [_p, _i, _p, _p, _p]),
@@ -71,6 +73,7 @@ PROTOTYPES = {
     "fdtdhip_plan_enable_timing": (_i, [_p, _i]),
     "fdtdhip_plan_get_timing": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "fdtdhip_plan_get_timing_parts": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "fdtdhip_curl_E": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "fdtdhip_curl_H": (_i, [_p, _p, _i, _i, _i, _i, _p]),
 }

@@ -194,9 +194,9 @@ struct fdtdhip_plan {
   // optional kernel timing (fdtdhip_plan_enable_timing)
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-  std::vector<int> ev_phase;  // phase (1 = E) of each used pair
-  double ms[2] = {0, 0};
-  int64_t launches[2] = {0, 0};
+  std::vector<int> ev_phase;  // what each used pair brackets (TIME_*)
+  double ms[4] = {0, 0, 0, 0};
+  int64_t launches[4] = {0, 0, 0, 0};
   size_t esize() const { return dtype == FDTDHIP_F32 ? 4 : 8; }
   int64_t cells() const { return (int64_t)nx * ny * nz; }
 };
@@ -426,12 +426,18 @@ int drain_timing(fdtdhip_plan* p) {
 template <typename T>
 int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1);
 
-template <typename T>
-int bulk(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
-  if (!p->timing || x0 == x1) return bulk_launch<T>(p, phaseE, x0, x1);
+// What a pair of timing events brackets: a bulk half-step launch (H, E), a whole-step kernel
+// (step_march, step_march_box, step_fused), or the half-step launches over the shell that
+// accompany the marching kernel on plans with PMLs, objects or open slab faces.
+enum { TIME_H = 0, TIME_E = 1, TIME_WHOLE = 2, TIME_SHELL = 3 };
+
+// First event of a timed span; `slot` names the pair for span_end.  No-ops unless timing is on.
+int span_begin(fdtdhip_plan* p, size_t& slot) {
+  slot = 0;
+  if (!p->timing) return 0;
   if (p->ev_phase.size() >= 2048)
     if (int rc = drain_timing(p)) return rc;
-  const size_t slot = p->ev_phase.size();
+  slot = p->ev_phase.size();
   if (slot >= p->ev_pool.size()) {
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a));
@@ -439,9 +445,22 @@ int bulk(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
     p->ev_pool.push_back({a, b});
   }
   HIPCHK(hipEventRecord(p->ev_pool[slot].first, p->stream));
-  const int rc = bulk_launch<T>(p, phaseE, x0, x1);
+  return 0;
+}
+int span_end(fdtdhip_plan* p, size_t slot, int what) {
+  if (!p->timing) return 0;
   HIPCHK(hipEventRecord(p->ev_pool[slot].second, p->stream));
-  p->ev_phase.push_back(phaseE ? 1 : 0);
+  p->ev_phase.push_back(what);
+  return 0;
+}
+
+template <typename T>
+int bulk(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
+  if (!p->timing || x0 == x1) return bulk_launch<T>(p, phaseE, x0, x1);
+  size_t slot;
+  if (int rc = span_begin(p, slot)) return rc;
+  const int rc = bulk_launch<T>(p, phaseE, x0, x1);
+  if (int rc2 = span_end(p, slot, phaseE ? TIME_E : TIME_H)) return rc2;
   return rc;
 }
 
@@ -1169,6 +1188,10 @@ bool march_core(const fdtdhip_plan* p, int (&core)[6], int (&hole)[6]) {
   BulkArgs<float> b;
   fill_core<float>(p, b);
   for (int n = 0; n < 6; ++n) core[n] = b.core[n];
+  // on an x-slab the plane that reads the neighbour's H (E half step of plane 0) or E (H half
+  // step of the last plane) waits for the halo exchange: it belongs to the shell
+  if (p->H_below) core[0] = std::max(core[0], 1);
+  if (p->E_above) core[1] = std::min(core[1], p->nx - 1);
   for (int ax = 0; ax < 3; ++ax) {
     if (core[2 * ax + 1] - core[2 * ax] < 1) return false;
     hole[2 * ax] = std::min(std::max(b.hull[2 * ax], core[2 * ax]), core[2 * ax + 1]);
@@ -1188,7 +1211,9 @@ bool march_owns(const fdtdhip_plan* p, const int (&core)[6], const int (&hole)[6
   return !(i >= hole[0] && i < hole[1] && j >= hole[2] && j < hole[3] && k >= hole[4] && k < hole[5]);
 }
 
-FusedKind fused_kind(const fdtdhip_plan* p) {
+// `staged`: asked by fdtdhip_step_stage, the whole step in pieces around the halo exchanges
+// of an x-slab -- the marching step or nothing.
+FusedKind fused_kind(const fdtdhip_plan* p, bool staged = false) {
   // FDTDHIP_FUSED=0 never, =1 step_fused whenever possible, =2 step_march whenever possible
   // (tests).  By default step_fused only where it was measured faster than two half-step
   // launches (MI355X, PML on every face, tools/mid_cost.py): 2-D grids up to about 420 x 420
@@ -1205,7 +1230,11 @@ FusedKind fused_kind(const fdtdhip_plan* p) {
   if (mode == 0 || !p->E_alt || !p->H_alt) return FUSED_NONE;
   for (const ObjH& o : p->objs)
     if (o.kind == FDTDHIP_OBJ_ANISOTROPIC_MODULATED) return FUSED_NONE;  // only the generic E kernel has them
-  if (p->H_below || p->E_above) return FUSED_NONE;
+  const bool halo = p->H_below || p->E_above;
+  if (halo && !staged) return FUSED_NONE;
+  if (staged && p->trace_cursor >= 0) return FUSED_NONE;   // recorded runs on slabs: half steps
+  for (const DetH& d : p->dets)
+    if (staged && d.below) return FUSED_NONE;   // read between the post pieces and a plane exchange
   for (const BoundaryRef& b : p->boundaries)
     if (b.kind == 1) return FUSED_NONE;
   for (const PmlH& h : p->pmls)
@@ -1219,16 +1248,20 @@ FusedKind fused_kind(const fdtdhip_plan* p) {
   const bool cell_ok = p->nx <= 65535 && (int64_t)p->ny * p->nz < (1ll << 30) &&
                        p->cells() * 3 < (1ll << 31);   // the kernel's element offsets are 32-bit
   int core[6], hole[6] = {0, 0, 0, 0, 0, 0};
-  const bool march_ok = ((p->pmls.empty() && p->objs.empty()) || march_core(p, core, hole)) &&
+  const bool whole_grid = p->pmls.empty() && p->objs.empty() && !halo;   // step_march, no shell
+  const bool march_ok = (whole_grid || march_core(p, core, hole)) &&
                         p->nz <= 64 * MARCH_MAX_WAVES && p->nx / 16 <= 65535;
   // the cells that take half steps of their own next to the marching kernel
-  const int64_t shell_cells = p->pmls.empty() && p->objs.empty() ? 0 :
+  const int64_t shell_cells = whole_grid || !march_ok ? 0 :
       p->cells() - (int64_t)(core[1] - core[0]) * (core[3] - core[2]) * (core[5] - core[4]) +
       (int64_t)(hole[1] - hole[0]) * (hole[3] - hole[2]) * (hole[5] - hole[4]);
-  if (mode == 1) return cell_ok ? FUSED_CELL : FUSED_NONE;
+  if (mode == 1) return cell_ok && !staged ? FUSED_CELL : FUSED_NONE;
   if (mode == 2) return march_ok ? FUSED_MARCH : FUSED_NONE;
   const int thin = std::min(p->nx, std::min(p->ny, p->nz));
-  if (cell_ok && p->cells() <= FUSED_AUTO_MAX_CELLS && thin == 1) return FUSED_CELL;
+  if (cell_ok && !staged && p->cells() <= FUSED_AUTO_MAX_CELLS && thin == 1) return FUSED_CELL;
+  // (with material arrays to read, the shell's half steps cost more than the marching kernel
+  // saves: 512^3 float32, six faces and two 64^3 boxes, 2.44 against 2.26 ms per step)
+  if (!(p->mat_const[0] && p->mat_const[1]) && !(p->pmls.empty() && p->objs.empty())) return FUSED_NONE;
   // (PML faces and objects: the shell and the box of the objects take half steps of their
   // own at a third of the marching kernel's rate per cell -- worth it while they are few)
   if (march_ok && p->nz >= 128 && p->ny >= 64 && p->nx >= 64 && p->cells() >= (1ll << 22) &&
@@ -1289,6 +1322,7 @@ int launch_march(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
   constexpr int TY = sizeof(T) == 4 ? 4 : 2;
   MarchArgs<T> m;
   m.s = a;
+  m.chunk0 = 0;
   const int tiles = (p->ny + TY - 1) / TY;
   // chunks of planes short enough for about four workgroups per CU, 16 planes at least
   int lx = (int)std::min<int64_t>(128, std::max<int64_t>(16, (int64_t)p->nx * tiles / 1024));
@@ -1318,27 +1352,36 @@ int launch_march(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
   return 0;
 }
 
-// The marching step of a plan with PML faces and/or objects: E half step of the shell, the
-// marching kernel over the core, H half step of the shell (yee_shell.hpp).
+// The marching step of a plan with PML faces, objects or open slab faces, in pieces: E half
+// step of the shell, the marching kernel over the core, H half step of the shell
+// (yee_shell.hpp).  On an x-slab two planes wait for a neighbour's plane -- plane 0 in the E
+// half step, the last plane in the H half step -- and the marching kernel comes in two
+// launches over halves of its chunks of planes, so that a caller can run
+//   E of the shell without plane 0, first half of the core      while H_below arrives,
+//   E of plane 0                                                 (then sends its new E),
+//   second half of the core, H of the shell without the last plane   while E_above arrives,
+//   H of the last plane.
+// The marching kernel reads the new E of plane 0 nowhere (its lowest plane is plane 1 at
+// least, whose H half step reads plane 2), so the order is that of two half steps for every
+// operand.  Without open faces all pieces are enqueued at once, the core in one launch.
+enum { ST_E_FREE = 1, ST_MARCH_A = 2, ST_E_GHOST = 4, ST_MARCH_B = 8, ST_H_FREE = 16, ST_H_GHOST = 32,
+       ST_ALL = 63 };
+
 template <typename T>
-int launch_march_shell(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
+int launch_march_shell(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, int stages) {
   constexpr int TY = sizeof(T) == 4 ? 4 : 2;
   int c[6], hole[6];
   if (!march_core(p, c, hole)) return fail(-1, "internal: no core box for the marching step");
   const int nx = p->nx, ny = p->ny, nz = p->nz;
+  const int e_lo = p->H_below ? 1 : 0;        // E half step: plane 0 waits for H_below
+  const int h_hi = p->E_above ? nx - 1 : nx;  // H half step: the last plane waits for E_above
   // the shell as disjoint boxes: x slabs over everything, y slabs between them, z slabs
   // inside; and the box of the objects, for the E half step only
-  const ShellBox boxes[MAX_SHELL_BOXES] = {
-      {0, c[0], 0, ny, 0, nz},           {c[1], nx, 0, ny, 0, nz},
-      {c[0], c[1], 0, c[2], 0, nz},      {c[0], c[1], c[3], ny, 0, nz},
-      {c[0], c[1], c[2], c[3], 0, c[4]}, {c[0], c[1], c[2], c[3], c[5], nz},
-      {hole[0], hole[1], hole[2], hole[3], hole[4], hole[5]}};
-  auto table = [&](int nboxes) {
+  auto table = [&](std::initializer_list<ShellBox> boxes) {
     Shell sh;
     sh.count = 0;
     sh.first[0] = 0;
-    for (int nb = 0; nb < nboxes; ++nb) {
-      const ShellBox& b = boxes[nb];
+    for (const ShellBox& b : boxes) {
       const int64_t n = (int64_t)std::max(b.i1 - b.i0, 0) * std::max(b.j1 - b.j0, 0) * std::max(b.k1 - b.k0, 0);
       if (n == 0) continue;
       sh.box[sh.count] = b;
@@ -1351,84 +1394,109 @@ int launch_march_shell(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
     }
     return sh;
   };
-  const Shell shE = table(MAX_SHELL_BOXES), shH = table(MAX_SHELL_BOXES - 1);
+  const ShellBox ylow{c[0], c[1], 0, c[2], 0, nz}, yhigh{c[0], c[1], c[3], ny, 0, nz},
+      zlow{c[0], c[1], c[2], c[3], 0, c[4]}, zhigh{c[0], c[1], c[2], c[3], c[5], nz};
   const bool pml = !p->pmls.empty();
-  if (shE.count) {
-    const dim3 grid((unsigned)shE.first[shE.count]), block(256);
-    if (pml && obj) hipLaunchKernelGGL((shell_E<T, true, true>), grid, block, 0, p->stream, a.e, a.E1, shE);
-    else if (pml) hipLaunchKernelGGL((shell_E<T, true, false>), grid, block, 0, p->stream, a.e, a.E1, shE);
-    else hipLaunchKernelGGL((shell_E<T, false, true>), grid, block, 0, p->stream, a.e, a.E1, shE);
-  }
+  size_t slot;
+  auto shell_e = [&](const Shell& sh) -> int {
+    if (!sh.count) return 0;
+    if (int rc = span_begin(p, slot)) return rc;
+    const dim3 grid((unsigned)sh.first[sh.count]), block(256);
+    if (pml && obj) hipLaunchKernelGGL((shell_E<T, true, true>), grid, block, 0, p->stream, a.e, a.E1, sh);
+    else if (pml) hipLaunchKernelGGL((shell_E<T, true, false>), grid, block, 0, p->stream, a.e, a.E1, sh);
+    else if (obj) hipLaunchKernelGGL((shell_E<T, false, true>), grid, block, 0, p->stream, a.e, a.E1, sh);
+    else hipLaunchKernelGGL((shell_E<T, false, false>), grid, block, 0, p->stream, a.e, a.E1, sh);
+    HIPCHK(hipGetLastError());
+    return span_end(p, slot, TIME_SHELL);
+  };
+  auto shell_h = [&](const Shell& sh) -> int {
+    if (!sh.count) return 0;
+    if (int rc = span_begin(p, slot)) return rc;
+    BulkArgs<T> h = a.h;
+    h.G = a.E1;     // the H half step is driven by the new E
+    const dim3 grid((unsigned)sh.first[sh.count]), block(256);
+    if (pml) hipLaunchKernelGGL((shell_H<T, true>), grid, block, 0, p->stream, h, a.H1, sh);
+    else hipLaunchKernelGGL((shell_H<T, false>), grid, block, 0, p->stream, h, a.H1, sh);
+    HIPCHK(hipGetLastError());
+    return span_end(p, slot, TIME_SHELL);
+  };
   // source points: the marching kernel adds those on cells whose E half step it evaluates,
-  // the others are added to the shell's new E here
+  // the others are added to the shell's new E once that is written (plane 0 of an open slab
+  // apart from the rest)
   MarchArgs<T> m;
   m.s = a;
-  ShellSources<T> ss;
-  ss.n = m.s.nsrc = 0;
+  ShellSources<T> ss_free, ss_ghost;
+  ss_free.n = ss_ghost.n = m.s.nsrc = 0;
+  const int64_t plane3 = (int64_t)ny * nz * 3;
   for (int n = 0; n < a.nsrc; ++n) {
     if (march_owns(p, c, hole, a.src_elem[n])) {
       m.s.src_elem[m.s.nsrc] = a.src_elem[n];
       m.s.src_value[m.s.nsrc++] = a.src_value[n];
     } else {
+      ShellSources<T>& ss = e_lo && a.src_elem[n] < plane3 ? ss_ghost : ss_free;
       ss.elem[ss.n] = a.src_elem[n];
       ss.value[ss.n++] = a.src_value[n];
     }
   }
-  if (ss.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, a.E1, ss);
-  for (int n = 0; n < 6; ++n) { m.box[n] = c[n]; m.hole[n] = hole[n]; }
-  const bool holed = hole[1] > hole[0];
-  const int tiles = (c[3] - c[2] + TY - 1) / TY, planes = c[1] - c[0];
-  // chunks of planes: as many as give two rounds of two workgroups per CU, not a few more
-  const int chunks = std::max(1, 1024 / tiles);
-  const int lx = m.lx = std::min(128, std::max(16, (planes + chunks - 1) / chunks));
-  const int waves = (nz + 63) / 64;
-  m.band = tiles >= 16 ? (tiles + 7) / 8 : 0;
-  const dim3 grid(m.band ? 8 * m.band : tiles, (planes + lx - 1) / lx, 1), block(64 * waves);
-  const bool constants = p->mat_const[0] && p->mat_const[1];
+  if (stages & ST_E_FREE) {
+    if (int rc = shell_e(table({{e_lo, c[0], 0, ny, 0, nz}, {c[1], nx, 0, ny, 0, nz}, ylow, yhigh, zlow, zhigh,
+                                {hole[0], hole[1], hole[2], hole[3], hole[4], hole[5]}})))
+      return rc;
+    if (ss_free.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, a.E1, ss_free);
+  }
+  if (stages & ST_E_GHOST) {
+    if (int rc = shell_e(table({{0, e_lo, 0, ny, 0, nz}}))) return rc;
+    if (ss_ghost.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, a.E1, ss_ghost);
+  }
+  if (stages & (ST_MARCH_A | ST_MARCH_B)) {
+    for (int n = 0; n < 6; ++n) { m.box[n] = c[n]; m.hole[n] = hole[n]; }
+    const bool holed = hole[1] > hole[0];
+    const int tiles = (c[3] - c[2] + TY - 1) / TY, planes = c[1] - c[0];
+    // chunks of planes: as many as give two rounds of two workgroups per CU, not a few more
+    const int chunks = std::max(1, 1024 / tiles);
+    const int lx = m.lx = std::min(128, std::max(16, (planes + chunks - 1) / chunks));
+    const int nchunks = (planes + lx - 1) / lx, half = nchunks / 2;
+    const int waves = (nz + 63) / 64;
+    m.band = tiles >= 16 ? (tiles + 7) / 8 : 0;
+    const bool both = (stages & ST_MARCH_A) && (stages & ST_MARCH_B);
+    m.chunk0 = both || (stages & ST_MARCH_A) ? 0 : half;
+    const int count = both ? nchunks : ((stages & ST_MARCH_A) ? half : nchunks - half);
+    if (count > 0) {
+      const dim3 grid(m.band ? 8 * m.band : tiles, count, 1), block(64 * waves);
+      const bool constants = p->mat_const[0] && p->mat_const[1];
+      if (int rc = span_begin(p, slot)) return rc;
 #define MARCH(MW)                                                                                     \
   if (holed && constants) hipLaunchKernelGGL((step_march_box<T, TY, true, true, MW>), grid, block, 0, p->stream, m); \
   else if (holed) hipLaunchKernelGGL((step_march_box<T, TY, true, false, MW>), grid, block, 0, p->stream, m); \
   else if (constants) hipLaunchKernelGGL((step_march_box<T, TY, false, true, MW>), grid, block, 0, p->stream, m); \
   else hipLaunchKernelGGL((step_march_box<T, TY, false, false, MW>), grid, block, 0, p->stream, m);
-  if (waves <= 8) { MARCH(8) } else { MARCH(MARCH_MAX_WAVES) }
+      if (waves <= 8) { MARCH(8) } else { MARCH(MARCH_MAX_WAVES) }
 #undef MARCH
-  if (shH.count) {
-    BulkArgs<T> h = a.h;
-    h.G = a.E1;     // the H half step is driven by the new E
-    hipLaunchKernelGGL((shell_H<T, true>), dim3((unsigned)shH.first[shH.count]), dim3(256), 0, p->stream, h, a.H1, shH);
+      HIPCHK(hipGetLastError());
+      if (int rc = span_end(p, slot, TIME_WHOLE)) return rc;
+    }
   }
+  if (stages & ST_H_FREE)
+    if (int rc = shell_h(table({{0, c[0], 0, ny, 0, nz}, {c[1], h_hi, 0, ny, 0, nz}, ylow, yhigh, zlow, zhigh})))
+      return rc;
+  if (stages & ST_H_GHOST)
+    if (int rc = shell_h(table({{h_hi, nx, 0, ny, 0, nz}}))) return rc;
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
+// Kernel arguments of a whole step at time index q (both half steps, the second buffers,
+// the additive source points with their values).
 template <typename T>
-int fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {
+int step_args(fdtdhip_plan* p, int64_t q, bool march, StepArgs<T>& a) {
   if (int rc = sync_obj_table<T>(p)) return rc;
-  const bool march = kind == FUSED_MARCH;   // reads no detectors itself
-  if (!march && p->detmap_state == 0)
-    if (int rc = build_detmap(p)) return rc;
-  StepArgs<T> a;
-  a.detmap = nullptr;
-  if (!march && p->detmap_state == 1) {
-    int slot = 0;
-    for (DetH& d : p->dets) {
-      if (d.kind != FDTDHIP_DET_CELLS || d.n == 0) continue;
-      if (!d.outE || !d.outH || d.usedE >= d.capacity || d.usedH >= d.capacity)
-        return fail(-3, "detector output capacity exhausted");
-      if (slot >= MAX_STEP_DETECTORS) return fail(-1, "detector map out of date");
-      a.detE[slot] = (T*)d.outE + d.usedE * d.n * 3;
-      a.detH[slot] = (T*)d.outH + d.usedH * d.n * 3;
-      ++slot;
-    }
-    for (; slot < MAX_STEP_DETECTORS; ++slot) a.detE[slot] = a.detH[slot] = nullptr;
-    a.detmap = p->detmap;
-  }
   for (int phase = 0; phase < 2; ++phase) {
     const bool phaseE = phase == 0;
     BulkArgs<T>& b = phaseE ? a.e : a.h;
     b.F = (T*)(phaseE ? p->E : p->H);
     b.G = (const T*)(phaseE ? p->H : p->E);
     b.mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
-    b.ghost = nullptr;
+    b.ghost = (const T*)(phaseE ? p->H_below : p->E_above);   // (open slab faces: marching step only)
     b.nx = p->nx; b.ny = p->ny; b.nz = p->nz;
     b.x0 = 0; b.x1 = p->nx;
     b.sc = (T)p->sc;
@@ -1447,46 +1515,27 @@ int fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {
   a.E1 = (T*)p->E_alt;
   a.H1 = (T*)p->H_alt;
   a.nsrc = 0;
+  a.detmap = nullptr;
+  for (int slot = 0; slot < MAX_STEP_DETECTORS; ++slot) a.detE[slot] = a.detH[slot] = nullptr;
   for (const SourceH& s : p->sources) {
     const double w = waveform(s, q);
     for (int64_t i = 0; i < s.n; ++i) {
+      if (a.nsrc >= MAX_STEP_SOURCES) return fail(-1, "internal: too many source points for a whole step");
       a.src_elem[a.nsrc] = s.elem_host[i];
       a.src_value[a.nsrc] = (T)(s.profile_host[i] * w);
       ++a.nsrc;
     }
   }
-  const int64_t plane = (int64_t)p->ny * p->nz;
-  const dim3 grid((unsigned)((plane + 255) / 256), p->nx, 1), block(256);
-  const bool pml = a.e.npml > 0, obj = a.e.nobj > 0;
-  size_t slot = 0;
-  if (p->timing) {
-    if (p->ev_phase.size() >= 2048)
-      if (int rc = drain_timing(p)) return rc;
-    slot = p->ev_phase.size();
-    if (slot >= p->ev_pool.size()) {
-      hipEvent_t e0, e1;
-      HIPCHK(hipEventCreate(&e0));
-      HIPCHK(hipEventCreate(&e1));
-      p->ev_pool.push_back({e0, e1});
-    }
-    HIPCHK(hipEventRecord(p->ev_pool[slot].first, p->stream));
-  }
-  if (march) {
-    if (int rc = pml || obj ? launch_march_shell<T>(p, a, obj) : launch_march<T>(p, a, obj)) return rc;
-  } else if (pml && obj) hipLaunchKernelGGL((step_fused<T, true, true>), grid, block, 0, p->stream, a);
-  else if (pml) hipLaunchKernelGGL((step_fused<T, true, false>), grid, block, 0, p->stream, a);
-  else if (obj) hipLaunchKernelGGL((step_fused<T, false, true>), grid, block, 0, p->stream, a);
-  else hipLaunchKernelGGL((step_fused<T, false, false>), grid, block, 0, p->stream, a);
-  HIPCHK(hipGetLastError());
-  if (p->timing) {
-    HIPCHK(hipEventRecord(p->ev_pool[slot].second, p->stream));
-    p->ev_phase.push_back(1);
-  }
-  // the second buffers now hold the current state
+  return 0;
+}
+
+// What follows the kernels of a whole step: the second buffers now hold the current state.
+template <typename T>
+int step_finish(fdtdhip_plan* p, int64_t q, bool cells_read) {
   std::swap(p->E, p->E_alt);
   std::swap(p->H, p->H_alt);
   p->step_flipped = !p->step_flipped;  // psi_E follows through the two fused PML tables
-  if (a.detmap) {
+  if (cells_read) {
     // cell-list detectors were read by the kernel; empty ones and loop currents remain
     for (DetH& d : p->dets) {
       if (d.kind == FDTDHIP_DET_CELLS) { ++d.usedE; ++d.usedH; }
@@ -1496,6 +1545,56 @@ int fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {
   }
   if (int rc = post<T>(p, true, q, POST_FINISH)) return rc;
   return post<T>(p, false, q, POST_FINISH);
+}
+
+template <typename T>
+int fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {
+  const bool march = kind == FUSED_MARCH;   // reads no detectors itself
+  if (!march && p->detmap_state == 0)
+    if (int rc = build_detmap(p)) return rc;
+  StepArgs<T> a;
+  if (int rc = step_args<T>(p, q, march, a)) return rc;
+  if (!march && p->detmap_state == 1) {
+    int slot = 0;
+    for (DetH& d : p->dets) {
+      if (d.kind != FDTDHIP_DET_CELLS || d.n == 0) continue;
+      if (!d.outE || !d.outH || d.usedE >= d.capacity || d.usedH >= d.capacity)
+        return fail(-3, "detector output capacity exhausted");
+      if (slot >= MAX_STEP_DETECTORS) return fail(-1, "detector map out of date");
+      a.detE[slot] = (T*)d.outE + d.usedE * d.n * 3;
+      a.detH[slot] = (T*)d.outH + d.usedH * d.n * 3;
+      ++slot;
+    }
+    a.detmap = p->detmap;
+  }
+  const int64_t plane = (int64_t)p->ny * p->nz;
+  const dim3 grid((unsigned)((plane + 255) / 256), p->nx, 1), block(256);
+  const bool pml = a.e.npml > 0, obj = a.e.nobj > 0;
+  if (march && (pml || obj)) {
+    if (int rc = launch_march_shell<T>(p, a, obj, ST_ALL)) return rc;
+  } else {
+    size_t slot;
+    if (int rc = span_begin(p, slot)) return rc;
+    if (march) {
+      if (int rc = launch_march<T>(p, a, obj)) return rc;
+    } else if (pml && obj) hipLaunchKernelGGL((step_fused<T, true, true>), grid, block, 0, p->stream, a);
+    else if (pml) hipLaunchKernelGGL((step_fused<T, true, false>), grid, block, 0, p->stream, a);
+    else if (obj) hipLaunchKernelGGL((step_fused<T, false, true>), grid, block, 0, p->stream, a);
+    else hipLaunchKernelGGL((step_fused<T, false, false>), grid, block, 0, p->stream, a);
+    HIPCHK(hipGetLastError());
+    if (int rc = span_end(p, slot, TIME_WHOLE)) return rc;
+  }
+  return step_finish<T>(p, q, a.detmap != nullptr);
+}
+
+// One piece of a whole step on an x-slab (fdtdhip_step_stage).
+template <typename T>
+int staged_step(fdtdhip_plan* p, int64_t q, int stage) {
+  StepArgs<T> a;
+  if (int rc = step_args<T>(p, q, true, a)) return rc;
+  static const int pieces[4] = {ST_E_FREE | ST_MARCH_A, ST_E_GHOST, ST_MARCH_B | ST_H_FREE, ST_H_GHOST};
+  if (int rc = launch_march_shell<T>(p, a, a.e.nobj > 0, pieces[stage])) return rc;
+  return stage == 3 ? step_finish<T>(p, q, false) : 0;
 }
 
 // ---- reverse sweep without allocations (fdtdhip_adjoint_run_noalloc) -----------------
@@ -2052,6 +2151,36 @@ int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
   return 0;
 }
 
+int fdtdhip_plan_whole_step_kind(fdtdhip_plan* p, int staged, int32_t core[6], int32_t hole[6]) {
+  if (!p) return fail(-1, "null plan");
+  const FusedKind kind = fused_kind(p, staged != 0);
+  int c[6] = {0, p->nx, 0, p->ny, 0, p->nz}, h[6] = {0, 0, 0, 0, 0, 0};
+  const bool shell = !(p->pmls.empty() && p->objs.empty()) || p->H_below || p->E_above;
+  if (kind == FUSED_MARCH && shell && !march_core(p, c, h)) return fail(-1, "internal: no core box");
+  for (int n = 0; n < 6; ++n) {
+    if (core) core[n] = c[n];
+    if (hole) hole[n] = h[n];
+  }
+  return (int)kind;
+}
+
+int fdtdhip_step_stage(fdtdhip_plan* p, int64_t q, int stage) {
+  if (!p) return fail(-1, "null plan");
+  if (stage < 0 || stage > 3) return fail(-1, "stage is 0..3");
+  GUARD(p);
+  if (p->poisoned) return fail(-5, kPoisoned);
+  if (stage == 0) {
+    if (!p->E || !p->H || !p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
+    if (fused_kind(p, true) != FUSED_MARCH)
+      return fail(-1, "this plan cannot take whole steps in stages (fdtdhip_plan_whole_step_kind)");
+    if (int rc = capacity_check(p, 1)) return rc;
+  }
+  const int rc = DISPATCH(p, staged_step<float>(p, q, stage), staged_step<double>(p, q, stage));
+  // (memory variables are advanced in place: a step that stops half way cannot be repeated)
+  if (rc) p->poisoned = true;
+  return rc;
+}
+
 int fdtdhip_plan_set_object_trace(fdtdhip_plan* p, int id, void* trace, int64_t capacity) {
   if (!p) return fail(-1, "null plan");
   if (id < 0 || id >= (int)p->objs.size()) return fail(-1, "unknown object id");
@@ -2172,22 +2301,33 @@ int fdtdhip_plan_enable_timing(fdtdhip_plan* p, int on) {
   GUARD(p);
   if (int rc = drain_timing(p)) return rc;
   p->timing = on != 0;
-  p->ms[0] = p->ms[1] = 0;
-  p->launches[0] = p->launches[1] = 0;
+  for (int n = 0; n < 4; ++n) { p->ms[n] = 0; p->launches[n] = 0; }
+  return 0;
+}
+
+int fdtdhip_plan_get_timing_parts(fdtdhip_plan* p, double ms[4], int64_t launches[4]) {
+  if (!p) return fail(-1, "null plan");
+  GUARD(p);
+  if (int rc = drain_timing(p)) return rc;
+  for (int n = 0; n < 4; ++n) {
+    if (ms) ms[n] = p->ms[n];
+    if (launches) launches[n] = p->launches[n];
+    p->ms[n] = 0;
+    p->launches[n] = 0;
+  }
   return 0;
 }
 
 int fdtdhip_plan_get_timing(fdtdhip_plan* p, double* ms_E, int64_t* launches_E, double* ms_H,
                             int64_t* launches_H) {
-  if (!p) return fail(-1, "null plan");
-  GUARD(p);
-  if (int rc = drain_timing(p)) return rc;
-  if (ms_E) *ms_E = p->ms[1];
-  if (launches_E) *launches_E = p->launches[1];
-  if (ms_H) *ms_H = p->ms[0];
-  if (launches_H) *launches_H = p->launches[0];
-  p->ms[0] = p->ms[1] = 0;
-  p->launches[0] = p->launches[1] = 0;
+  double ms[4];
+  int64_t n[4];
+  if (int rc = fdtdhip_plan_get_timing_parts(p, ms, n)) return rc;
+  // whole-step kernels and their shell launches are reported with the E half step
+  if (ms_E) *ms_E = ms[TIME_E] + ms[TIME_WHOLE] + ms[TIME_SHELL];
+  if (launches_E) *launches_E = n[TIME_E] + n[TIME_WHOLE];
+  if (ms_H) *ms_H = ms[TIME_H];
+  if (launches_H) *launches_H = n[TIME_H];
   return 0;
 }
 

@@ -47,6 +47,8 @@ struct MarchArgs {
   int band;        // tiles per XCD (grid x = 8 * band), or 0: tile = blockIdx.x
   int box[6];      // step_march_box: x0, x1, y0, y1, z0, z1 of the cells to advance
   int hole[6];     // step_march_box: a box inside `box` whose E half step is not this kernel's
+  int chunk0;      // step_march_box: first chunk of planes of this launch (a launch may take a
+                   // part of the chunks: the others belong to another launch of the same step)
 };
 
 // Additive point sources on the new E of one cell (reference fdtd/grid.py:293-295).
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(64 * MW) void step_march_box(MarchArgs<T> ma) {
   const int tile = ma.band > 0 ? (int)(blockIdx.x & 7) * ma.band + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int j0 = by0 + tile * TY;
   if (j0 >= by1) return;
-  const int i0 = bx0 + blockIdx.y * ma.lx, i1 = min(i0 + ma.lx, bx1);
+  const int i0 = bx0 + ((int)blockIdx.y + ma.chunk0) * ma.lx, i1 = min(i0 + ma.lx, bx1);
   const int64_t sy = 3 * (int64_t)nz, sx = sy * ny;
   const T* __restrict__ H0 = A.G;
   const T* __restrict__ E0 = A.F;

@@ -85,13 +85,17 @@ __global__ __launch_bounds__(256) void shell_E(BulkArgs<T> a, T* __restrict__ ou
   const T* __restrict__ gx = i > 0 ? g - sx : g;
   const T* __restrict__ gy = j > 0 ? g - sy : g;
   const T* __restrict__ gz = k > 0 ? g - sz : g;
+  // plane 0 of an x-slab takes the x neighbour's two components from the ghost plane
+  const bool from_ghost = i == 0 && a.ghost != nullptr;
+  const T* __restrict__ gh = from_ghost ? a.ghost + ((int64_t)j * a.nz + k) * 2 : gx + 1;
+  const bool hasx = i > 0 || from_ghost;
   const T hx = g[0], hy = g[1], hz = g[2];
-  const T xy = gx[1], xz = gx[2], yx = gy[0], yz = gy[2], zx = gz[0], zy = gz[1];
+  const T xy = gh[0], xz = gh[1], yx = gy[0], yz = gy[2], zx = gz[0], zy = gz[1];
   T e[3] = {a.F[c3], a.F[c3 + 1], a.F[c3 + 2]};
   Diffs<T> d;
   d.y_z = j > 0 ? hz - yz : T(0); d.y_x = j > 0 ? hx - yx : T(0);
   d.z_y = k > 0 ? hy - zy : T(0); d.z_x = k > 0 ? hx - zx : T(0);
-  d.x_z = i > 0 ? hz - xz : T(0); d.x_y = i > 0 ? hy - xy : T(0);
+  d.x_z = hasx ? hz - xz : T(0); d.x_y = hasx ? hy - xy : T(0);
   T m[3];
   cell_material<T, false, HAS_OBJ>(a, c3, i, j, k, m);
   const T hs[3] = {hx, hy, hz};
@@ -108,13 +112,16 @@ __global__ __launch_bounds__(256) void shell_H(BulkArgs<T> a, T* __restrict__ ou
   if (!shell_lane_cell(b, i, j, k)) return;
   const int64_t sz = 3, sy = 3 * (int64_t)a.nz, sx = sy * a.ny;
   const int64_t c3 = (int64_t)i * sx + (int64_t)j * sy + 3 * k;
-  const bool ox = i < a.nx - 1, oy = j < a.ny - 1, oz = k < a.nz - 1;
+  // the last plane of an x-slab takes the x neighbour's two components from the ghost plane
+  const bool from_ghost = i == a.nx - 1 && a.ghost != nullptr;
+  const bool ox = i < a.nx - 1 || from_ghost, oy = j < a.ny - 1, oz = k < a.nz - 1;
   const T* __restrict__ g = a.G + c3;
-  const T* __restrict__ gx = ox ? g + sx : g;
+  const T* __restrict__ gx = i < a.nx - 1 ? g + sx : g;
   const T* __restrict__ gy = oy ? g + sy : g;
   const T* __restrict__ gz = oz ? g + sz : g;
+  const T* __restrict__ gh = from_ghost ? a.ghost + ((int64_t)j * a.nz + k) * 2 : gx + 1;
   const T ex = g[0], ey = g[1], ez = g[2];
-  const T xy = gx[1], xz = gx[2], yx = gy[0], yz = gy[2], zx = gz[0], zy = gz[1];
+  const T xy = gh[0], xz = gh[1], yx = gy[0], yz = gy[2], zx = gz[0], zy = gz[1];
   T h[3] = {a.F[c3], a.F[c3 + 1], a.F[c3 + 2]};
   Diffs<T> d;
   d.y_z = oy ? yz - ez : T(0); d.y_x = oy ? yx - ex : T(0);

@@ -522,12 +522,12 @@ class Grid:
         _lib.check(lib.fdtdhip_adjoint_cells(self._plan, phase, 0, p(lamE), p(lamH), p(work)))
         _lib.check(lib.fdtdhip_adjoint_gather(self._plan, phase, p(lamE), p(lamH), p(work), None))
 
-    def _provide_step_buffers(self):
+    def _provide_step_buffers(self, slab=False):
         """Second E/H (and PML psi_E) buffers that let ``run`` use the fused full-step
         kernel; allocated once, and only for scenes the native library can fuse (no
         periodic boundary other than along an axis of one cell, where the copy is the
         identity; no plane source; few additive source points)."""
-        if getattr(self, "_step_buffers", None) is not None or self.Nx != self.Nx_global:
+        if getattr(self, "_step_buffers", None) is not None or (self.Nx != self.Nx_global and not slab):
             return
         points = 0
         for b in self.boundaries:

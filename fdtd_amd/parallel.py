@@ -72,6 +72,15 @@ class _NativeEngine:
     def post_H_stage(self, q, stage):
         _lib.check(self.lib.fdtdhip_update_H_post_stage(self.plan, q, stage))
 
+    def whole_steps_possible(self):
+        """Whether this slab's plan can advance whole steps in stages (``fdtdhip_step_stage``):
+        second buffers provided, nothing between the half steps that the whole-step kernel
+        cannot do, and a grid large enough for it to pay."""
+        return self.lib.fdtdhip_plan_whole_step_kind(self.plan, 1, None, None) == 2
+
+    def step_stage(self, q, stage):
+        _lib.check(self.lib.fdtdhip_step_stage(self.plan, q, stage))
+
     def defer_currents(self, plane):
         """Current detectors wait for ``plane`` (the H plane under this slab) instead of
         being read with the other detectors; None: read them with the others."""
@@ -120,6 +129,7 @@ class SlabGrid(Grid):
         self._send_H = bd.zeros(plane) if self._rank < self._world - 1 else None
         self._send_E = bd.zeros(plane) if self._rank > 0 else None
         self._engine = (engine_factory or _NativeEngine)(self)
+        self.whole_steps_taken = 0    # steps advanced by the whole-step kernel (diagnostics)
 
     # ------------------------------------------------------------ decomposition
     def _partition(self):
@@ -317,11 +327,60 @@ class SlabGrid(Grid):
             self.E = self.E.detach().requires_grad_(True)
         return wanted
 
+    def _whole_step(self, eng, q, cur, alt):
+        """One step from the buffers ``cur`` = (E, H) into ``alt`` in four pieces around the two
+        plane exchanges (``fdtdhip_step_stage``): while (Hy, Hz) of the rank below travel, the
+        cells that do not read them are advanced -- the E half step next to PMLs and objects
+        and half of the whole-step kernel; then plane 0 takes its E half step and its new
+        (Ey, Ez) travel to the rank below behind the other half of the whole-step kernel; the
+        last plane takes its H half step when (Ey, Ez) of the rank above have arrived."""
+        r, p = self._rank, self._world
+        ex = self._start_exchange(self._tangential(cur[1][-1], self._send_H) if r < p - 1 else None,
+                                  r + 1, self._H_below, r - 1)
+        eng.step_stage(q, 0)
+        if ex is not None:
+            ex.wait()
+        eng.step_stage(q, 1)
+        ex = self._start_exchange(self._tangential(alt[0][0], self._send_E) if r > 0 else None,
+                                  r - 1, self._E_above, r + 1)
+        eng.step_stage(q, 2)
+        if ex is not None:
+            ex.wait()
+        eng.step_stage(q, 3)
+
+    def _whole_steps_agreed(self, eng, n):
+        """Collective: whether the coming ``n`` steps are taken as whole steps in stages.  The
+        two ways of stepping exchange planes at different moments, so every rank has to take
+        the same one: the one-launch step only if every rank's plan can."""
+        if n < 2 or not hasattr(eng, "whole_steps_possible"):
+            return False
+        mine = (getattr(self, "_step_buffers", None) is not None and not self._x_wrap
+                and not self._currents_cross_slabs and eng.whole_steps_possible())
+        if self._world == 1:
+            return mine
+        on_device = self._backend_name == "nccl"
+        flag = torch.tensor([1 if mine else 0], device=bd.device if on_device else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._group)
+        return bool(flag.item())
+
     def _native_run(self, lib, n):
         eng = self._engine
+        if n >= 2 and not bd.staging:
+            self._provide_step_buffers(slab=True)
         eng.prepare(n)
         eng.reserve_detectors(n, n)
-        for s in range(n):
+        s = 0
+        if self._whole_steps_agreed(eng, n):
+            # pairs of whole steps, first -> second buffers and back: the state ends in the
+            # tensors the user holds; an odd last step runs as two half steps
+            cur = (self.E.detach(), self.H.detach())
+            alt = self._step_buffers
+            while s + 1 < n:
+                self._whole_step(eng, self.time_steps_passed + s, cur, alt)
+                self._whole_step(eng, self.time_steps_passed + s + 1, alt, cur)
+                s += 2
+            self.whole_steps_taken += s
+        for s in range(s, n):
             q = self.time_steps_passed + s
             self._half_step_E(eng, q)
             self._half_step_H(eng, q)

@@ -257,6 +257,30 @@ int fdtdhip_plan_set_pml_step_buffer(fdtdhip_plan* plan, int id, void* psiE_alt)
 /* nsteps full steps starting at time index q0 (reference fdtd/grid.py:250-273). */
 int fdtdhip_run(fdtdhip_plan* plan, int64_t q0, int64_t nsteps);
 
+/* Whole steps on an x-slab (no reference counterpart: the reference is single device and
+ * always runs two passes per step, fdtd/grid.py:267-273).  With second buffers provided
+ * (fdtdhip_plan_set_step_buffers, fdtdhip_plan_set_pml_step_buffer) a slab whose plan
+ * fdtdhip_plan_whole_step_kind(plan, 1, ...) reports as 2 can advance a step in four pieces
+ * placed around the two plane exchanges of the step; between the pieces the caller moves
+ * the planes:
+ *   stage 0  E half step of the cells next to PMLs, objects and the high slab face, and the
+ *            first half of the whole-step kernel over the other cells -- needs neither ghost plane;
+ *   stage 1  E half step of plane 0, which reads H_below: the plane must have arrived.  The
+ *            new (Ey, Ez) of plane 0 are then in the second E buffer for the rank below;
+ *   stage 2  second half of the whole-step kernel, H half step of the shell without the last plane;
+ *   stage 3  H half step of the last plane, which reads E_above (arrived); then the buffers
+ *            swap (the second buffers hold the state, as after an odd number of fused
+ *            steps inside fdtdhip_run) and the detectors are read.
+ * Results equal fdtdhip_update_E + fdtdhip_update_H bit for bit.  Take steps in pairs so
+ * that the state ends in the first buffers; a failed stage poisons the plan (reset it).
+ * fdtdhip_plan_whole_step_kind: which whole-step kernel the plan would take -- 0 none, 1 the
+ * one-lane-per-cell kernel (small 2-D grids), 2 the marching kernel; `staged` != 0 asks for
+ * fdtdhip_step_stage (open slab faces allowed).  core / hole (may be NULL) receive the box
+ * {x0,x1,y0,y1,z0,z1} the marching kernel advances and the box inside it whose E half step
+ * it leaves to the shell launches (the objects). */
+int fdtdhip_plan_whole_step_kind(fdtdhip_plan* plan, int staged, int32_t core[6], int32_t hole[6]);
+int fdtdhip_step_stage(fdtdhip_plan* plan, int64_t q, int stage);
+
 /* ---- differentiable runs (backward through time) ---------------------------
  * The reference differentiates through grid.run with torch autograd, recording
  * every slice operation of every step (reference examples/learnable_focus.py:98-128,
@@ -380,6 +404,11 @@ int fdtdhip_plane_energy(fdtdhip_plan* plan, int axis, int index, void* outE, vo
 int fdtdhip_plan_enable_timing(fdtdhip_plan* plan, int on);
 int fdtdhip_plan_get_timing(fdtdhip_plan* plan, double* ms_E, int64_t* launches_E,
                             double* ms_H, int64_t* launches_H);
+/* The same, by kind of launch: [0] H bulk kernels, [1] E bulk kernels, [2] whole-step kernels
+ * (one launch advances E and H), [3] the half-step launches over the cells next to PMLs,
+ * objects and open slab faces that accompany a whole-step kernel.  fdtdhip_plan_get_timing
+ * reports [1] + [2] + [3] as the E time and [1] + [2] as the E launches. */
+int fdtdhip_plan_get_timing_parts(fdtdhip_plan* plan, double ms[4], int64_t launches[4]);
 
 /* Stand-alone curls (reference fdtd/grid.py:29-76): out = curl(in), both device
  * (nx,ny,nz,3) arrays of `dtype`; enqueued on `stream`. */

@@ -397,6 +397,92 @@ def test_random_scenes_on_slabs_gpu(tmp_path):
     _fuzz(3, 400, 90, True, tmp_path)
 
 
+def _large_slab_worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    import fdtd_amd as fdtd
+    from fdtd_amd.parallel import SlabGrid
+
+    slab_support.init_gloo(rank, world, port)
+    try:
+        fdtd.set_backend("hip.float32", device=0)
+        grid = SlabGrid((64 * world, 128, 512))
+        for key in ((slice(0, 4),), (slice(-4, None),), (slice(None), slice(0, 4)),
+                    (slice(None), slice(-4, None)), (slice(None), slice(None), slice(0, 4)),
+                    (slice(None), slice(None), slice(-4, None))):
+            grid[key] = fdtd.PML()
+        grid[64 * world // 2, 60, 250] = fdtd.PointSource(period=17)      # first plane of a slab
+        grid[64 * world // 2 - 1, 3, 300] = fdtd.PointSource(period=23)   # last plane, inside a PML
+        grid[20, 64, 100] = fdtd.PointSource(period=11)
+        grid[64 * world - 30:64 * world - 10, 30:50, 40:90] = fdtd.AbsorbingObject(
+            permittivity=2.0, conductivity=1e-2)
+        det = fdtd.LineDetector()
+        grid[5:64 * world - 5, 64, 256] = det
+        gen = torch.Generator(device=grid.E.device).manual_seed(77 + rank)
+        with torch.no_grad():
+            for f in (grid.E, grid.H):
+                f.uniform_(-1e-3, 1e-3, generator=gen)
+            grid.run(7, progress_bar=False)    # three pairs of whole steps, one step of half steps
+        torch.cuda.synchronize()
+        E, H = grid.gather("E"), grid.gather("H")
+        parts = [None] * world
+        dist.all_gather_object(parts, (fdtd.backend.numpy(torch.stack(det.E)), grid.whole_steps_taken))
+        if rank == 0:
+            np.savez(out, E=E, H=H, det=np.concatenate([p[0] for p in parts], axis=1),
+                     whole=np.array([p[1] for p in parts]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_large_slabs_take_whole_steps_by_default_and_equal_half_steps_bitwise(tmp_path, monkeypatch):
+    """Slabs of the size the default policy gives to the whole-step kernel (64 x 128 x 512
+    float32 per rank, thin PMLs on every face of the simulation, an object, sources on the
+    first and on the last plane of a slab): three ranks -- an interior slab with two open
+    faces between two end slabs -- against the same run with FDTDHIP_FUSED=0 (two half-step
+    launches per step), bit for bit, fields and detector readings."""
+    runs = {}
+    for mode in ("default", "0"):
+        if mode == "0":
+            monkeypatch.setenv("FDTDHIP_FUSED", "0")
+        out = str(tmp_path / f"large_{mode}.npz")
+        mp.spawn(_large_slab_worker, args=(3, slab_support.free_port(), out), nprocs=3, join=True)
+        runs[mode] = np.load(out)
+    assert list(runs["default"]["whole"]) == [6, 6, 6] and list(runs["0"]["whole"]) == [0, 0, 0]
+    for name in ("E", "H", "det"):
+        assert np.array_equal(runs["default"][name], runs["0"][name]), name
+    assert np.abs(runs["default"]["E"]).max() > 0
+
+
+@pytest.mark.gpu
+def test_random_scenes_on_slabs_whole_steps_gpu(tmp_path, monkeypatch):
+    """Slabs advanced by the whole-step kernel in stages around the two plane exchanges of a
+    step (fdtdhip_step_stage; FDTDHIP_FUSED=2 applies it at any size the plan allows, the
+    default is large 3-D slabs only): plane 0 and the last plane as shell cells that wait
+    for a ghost plane, the core in two launches, PMLs and objects in the shell, on two,
+    three and five ranks (slabs of one or two planes: no core left, half steps), in both
+    precisions and on extents of 40-128 cells."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import fuzz_slab as fz
+
+    monkeypatch.setenv("FDTDHIP_FUSED", "2")
+    _fuzz(3, 400, 90, True, tmp_path)
+    taken = fz.WHOLE_STEP_SCENES
+    _fuzz(2, 9000, 60, True, tmp_path)
+    taken += fz.WHOLE_STEP_SCENES
+    monkeypatch.setenv("FUZZ_BIG", "1")
+    _fuzz(2, 1000, 16, True, tmp_path)
+    taken += fz.WHOLE_STEP_SCENES
+    monkeypatch.setenv("FUZZ_FLOAT32", "1")
+    _fuzz(3, 1100, 16, True, tmp_path)
+    taken += fz.WHOLE_STEP_SCENES
+    monkeypatch.delenv("FUZZ_BIG")
+    monkeypatch.delenv("FUZZ_FLOAT32")
+    monkeypatch.setenv("FUZZ_THIN_X", "5")
+    _fuzz(5, 100, 20, True, tmp_path)
+    assert taken >= 30, taken
+
+
 @pytest.mark.gpu
 def test_random_scenes_slab_gradients_gpu(tmp_path):
     """Differentiable runs of random scenes on three slabs -- the learnable object anywhere,

@@ -128,6 +128,7 @@ def worker(rank, world, port, seeds, on_gpu, out, crowded=None):
             dist.all_gather_object(parts, mine)
             if rank == 0:
                 results[f"E{seed}"], results[f"H{seed}"] = E, H
+                results[f"whole{seed}"] = np.array(getattr(grid, "whole_steps_taken", 0))
                 for key in mine:   # the ranks hold consecutive cells of the detector
                     results[f"{key}_{seed}"] = np.concatenate([p[key] for p in parts], axis=1)
         if rank == 0:
@@ -156,11 +157,16 @@ def oracle_results(scene):
     return want
 
 
+WHOLE_STEP_SCENES = 0
+
+
 def run(world, first, count, on_gpu, out, crowded=None):
     seeds = [s for s in range(first, first + count) if usable(make_scene(s, crowded), world, on_gpu)]
     mp.spawn(worker, args=(world, slab_support.free_port(), seeds, on_gpu, out, crowded), nprocs=world, join=True)
     z = np.load(out)
     bad = {}
+    global WHOLE_STEP_SCENES   # scenes in which rank 0 advanced by whole steps in stages
+    WHOLE_STEP_SCENES = sum(int(z[f"whole{seed}"]) > 0 for seed in seeds)
     for seed in seeds:
         for name, want in oracle_results(make_scene(seed, crowded)).items():
             got = z[f"{name}{seed}"] if name in ("E", "H") else z[f"{name}_{seed}"]
@@ -186,5 +192,6 @@ if __name__ == "__main__":
         print(f"seed {seed}: {errs}\n   {make_scene(seed)}")
     print(f"x{world} {'gpu' if on_gpu else 'cpu'}: {len(seeds)} scenes "
           f"({sum(crosses(make_scene(s), world) for s in seeds)} with a current loop across slabs), "
+          f"{WHOLE_STEP_SCENES} advanced by whole steps in stages, "
           f"{len(bad)} above {'1e-5' if flag('FLOAT32') else '1e-12'}")
     sys.exit(1 if bad else 0)

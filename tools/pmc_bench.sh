@@ -18,15 +18,20 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        name = next((n for n in ("bulk_E", "bulk_H", "step_march", "step_fused") if "fdtdhip::" + n in k), None)
+        name = next((n for n in ("bulk_E", "bulk_H", "step_march_box", "step_march", "step_fused", "shell_E", "shell_H")
+                     if "fdtdhip::" + n in k), None)
         if name is None: continue
         agg[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 tot = {}
+# the dominant kernels: the whole-step kernel where the run took it, else the two bulk kernels
+whole = [n for n in ("step_march_box", "step_march", "step_fused") if n in agg]
+dominant = whole[:1] or ["bulk_E", "bulk_H"]
 for name in sorted(agg):
     for c, v in sorted(agg[name].items()):
         v = v[len(v)//2:]  # later launches (steady state)
-        tot.setdefault(c, []).append(sum(v)/len(v))
+        if name in dominant:
+            tot.setdefault(c, []).append(sum(v)/len(v))
         print(f"{w} {name} {c}: mean {sum(v)/len(v):.6g} KB over {len(v)} launches")
 f = sum(tot["FETCH_SIZE"]) / len(tot["FETCH_SIZE"]); wr = sum(tot["WRITE_SIZE"]) / len(tot["WRITE_SIZE"])
-print(f"{w} per launch (mean over the kernels above): FETCH_SIZE {f:.0f} KB, WRITE_SIZE {wr:.0f} KB, bytes = (2*FETCH+WRITE)*1024 = {(2*f+wr)*1024:.0f}")
+print(f"{w} per launch (mean over {' and '.join(dominant)}): FETCH_SIZE {f:.0f} KB, WRITE_SIZE {wr:.0f} KB, bytes = (2*FETCH+WRITE)*1024 = {(2*f+wr)*1024:.0f}")
 PY

@@ -1,0 +1,73 @@
+"""Step time of ONE interior slab of the 8-GPU configuration on one GPU, with its plane
+exchanges: 256 x 1024 x 1024 float32, PMLs on the y and z faces, both x faces open.  The one
+rank is its own neighbour on both sides (a one-rank RCCL group sending the planes to
+itself), so the exchanges cost what RCCL's send/recv kernels and their stream
+synchronisation cost on one device -- no xGMI, but every launch, wait and copy of the real
+schedule.  FDTDHIP_FUSED=0 in the environment: two half-step launches per step (with the
+interior / boundary-plane split); default: whole steps in stages.
+
+    python tools/slab_step_cost.py [steps] [workload: m4 | m3v]
+"""
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29549")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+import fdtd_amd as fdtd  # noqa: E402
+from fdtd_amd.backend import backend as bd  # noqa: E402
+from fdtd_amd.parallel import SlabGrid  # noqa: E402
+
+
+class InteriorSlab(SlabGrid):
+    """A slab that believes it is rank 1 of 3 and exchanges planes with itself."""
+
+    def __init__(self, shape):
+        super().__init__(shape)
+        self._rank, self._world = 1, 3
+        plane = (self.Ny, self.Nz, 2)
+        self._H_below, self._E_above = bd.zeros(plane), bd.zeros(plane)
+        self._halo = (self._H_below, self._E_above)
+        self._send_H, self._send_E = bd.zeros(plane), bd.zeros(plane)
+
+    def _global_rank(self, r):
+        return 0
+
+    def _whole_steps_agreed(self, eng, n):
+        return (n >= 2 and getattr(self, "_step_buffers", None) is not None
+                and eng.whole_steps_possible())
+
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+workload = sys.argv[2] if len(sys.argv) > 2 else "m4"
+fdtd.set_backend("hip.float32", device=0)
+shape = (256, 1024, 1024) if workload == "m4" else (512, 512, 512)
+g = InteriorSlab(shape)
+if workload == "m4":
+    for key in ((slice(None), slice(0, 10)), (slice(None), slice(-10, None)),
+                (slice(None), slice(None), slice(0, 10)), (slice(None), slice(None), slice(-10, None))):
+        g[key] = fdtd.PML()
+g[shape[0] // 2, shape[1] // 2, shape[2] // 2] = fdtd.PointSource(period=20)
+gen = torch.Generator(device=g.E.device).manual_seed(1)
+with torch.no_grad():
+    for f in (g.E, g.H):
+        f.uniform_(-1e-3, 1e-3, generator=gen)
+    g.run(10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.run(steps)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+cells = shape[0] * shape[1] * shape[2]
+print(f"{workload} interior slab, FDTDHIP_FUSED={os.environ.get('FDTDHIP_FUSED', 'default')}: "
+      f"{(t2 - t0) / steps * 1e3:.3f} ms/step = {cells * steps / (t2 - t0) / 1e9:.1f} Gcells/s, "
+      f"host enqueue {(t1 - t0) / steps * 1e3:.3f} ms/step, whole steps taken {g.whole_steps_taken}",
+      flush=True)
+dist.destroy_process_group()
