@@ -1178,6 +1178,9 @@ constexpr int64_t FUSED_AUTO_MAX_CELLS = 1 << 17;
 //   FUSED_MARCH : step_march, workgroups marching along x -- wins on large 3-D grids, where
 //                 it moves 12 instead of 18 values per cell and step.
 enum FusedKind { FUSED_NONE = 0, FUSED_CELL, FUSED_MARCH };
+#ifndef FDTDHIP_MARCH_TY32
+#define FDTDHIP_MARCH_TY32 4   // rows per workgroup of the marching kernel in float32 (experiments: -D)
+#endif
 constexpr int64_t MARCH_SHELL_SHARE = 6;   // shell cells at most a sixth of the grid
 
 // Plans with PML faces take the marching step over the box no face reaches, with half steps
@@ -1319,7 +1322,7 @@ int build_detmap(fdtdhip_plan* p) {
 // with 2 rows, 6.2 ms with 3, against 1.81 ms for two half-step launches).
 template <typename T>
 int launch_march(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
-  constexpr int TY = sizeof(T) == 4 ? 4 : 2;
+  constexpr int TY = sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : 2;
   MarchArgs<T> m;
   m.s = a;
   m.chunk0 = 0;
@@ -1369,7 +1372,7 @@ enum { ST_E_FREE = 1, ST_MARCH_A = 2, ST_E_GHOST = 4, ST_MARCH_B = 8, ST_H_FREE 
 
 template <typename T>
 int launch_march_shell(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, int stages) {
-  constexpr int TY = sizeof(T) == 4 ? 4 : 2;
+  constexpr int TY = sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : 2;
   int c[6], hole[6];
   if (!march_core(p, c, hole)) return fail(-1, "internal: no core box for the marching step");
   const int nx = p->nx, ny = p->ny, nz = p->nz;

@@ -304,6 +304,8 @@ class SlabGrid(Grid):
         if not bd.staging and self._any_rank_needs_grad():
             autograd.differentiable_advance(self, n)
             return
+        if n >= 2 and not bd.staging:
+            self._provide_step_buffers(slab=True)
         self._native_run(None, n)
         self.time_steps_passed += n
 
@@ -365,12 +367,12 @@ class SlabGrid(Grid):
 
     def _native_run(self, lib, n):
         eng = self._engine
-        if n >= 2 and not bd.staging:
-            self._provide_step_buffers(slab=True)
         eng.prepare(n)
         eng.reserve_detectors(n, n)
         s = 0
-        if self._whole_steps_agreed(eng, n):
+        # (lib is None: called by _advance for a run that is not recorded; the forward pass of
+        # a recorded run keeps to half steps, whose curl traces its reverse sweep reads)
+        if lib is None and self._whole_steps_agreed(eng, n):
             # pairs of whole steps, first -> second buffers and back: the state ends in the
             # tensors the user holds; an odd last step runs as two half steps
             cur = (self.E.detach(), self.H.detach())
