@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfdtd_hip.so")
+# (FDTDHIP_LIBRARY: another build of the same library, for kernel experiments)
+LIB_PATH = os.environ.get("FDTDHIP_LIBRARY") or os.path.join(_HERE, "csrc", "libfdtd_hip.so")
 
 F32, F64 = 0, 1
 OBJ_ISOTROPIC, OBJ_ABSORBING, OBJ_ANISOTROPIC, OBJ_ANISOTROPIC_MODULATED = 0, 1, 2, 3

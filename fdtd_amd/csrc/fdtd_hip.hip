@@ -1181,6 +1181,9 @@ enum FusedKind { FUSED_NONE = 0, FUSED_CELL, FUSED_MARCH };
 #ifndef FDTDHIP_MARCH_TY32
 #define FDTDHIP_MARCH_TY32 4   // rows per workgroup of the marching kernel in float32 (experiments: -D)
 #endif
+#ifndef FDTDHIP_MARCH_TY64
+#define FDTDHIP_MARCH_TY64 4   // the same in float64
+#endif
 constexpr int64_t MARCH_SHELL_SHARE = 6;   // shell cells at most a sixth of the grid
 
 // Plans with PML faces take the marching step over the box no face reaches, with half steps
@@ -1315,14 +1318,14 @@ int build_detmap(fdtdhip_plan* p) {
   return 0;
 }
 
-// The marching step (yee_march.hpp): 4 rows per workgroup in float32, 2 in float64 (about 100
-// registers, 4 waves per SIMD).  Plans with PMLs do not take it: with the face code evaluated
-// row after row every workgroup waits, plane by plane, for its two waves on the z faces to
-// walk their chain of memory-variable round trips (512^3 float32, six faces: 4.6 ms per step
-// with 2 rows, 6.2 ms with 3, against 1.81 ms for two half-step launches).
-template <typename T>
-int launch_march(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
-  constexpr int TY = sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : 2;
+// The marching step (yee_march.hpp) over the whole grid: plans without PMLs, objects and
+// open slab faces.  (The kernel carries no PML code: with the face code evaluated row after
+// row every workgroup waited, plane by plane, for its two waves on the z faces to walk their
+// chain of memory-variable round trips -- 512^3 float32, six faces: 4.6 ms per step with 2
+// rows, 6.2 ms with 3, against 1.81 ms for two half-step launches.  Plans with faces split
+// off a shell instead, see launch_march_shell.)
+template <typename T, int TY, int MW>
+int launch_march_tiles(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
   MarchArgs<T> m;
   m.s = a;
   m.chunk0 = 0;
@@ -1346,13 +1349,23 @@ int launch_march(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
   const bool constants = p->mat_const[0] && p->mat_const[1];
   // (a kernel limited to 8 waves per workgroup may use 256 registers, one for z rows of up to
   // 1024 cells 128)
-#define MARCH(MW)                                                                                     \
-  if (obj) hipLaunchKernelGGL((step_march<T, TY, false, true, false, MW>), grid, block, 0, p->stream, m); \
-  else if (constants) hipLaunchKernelGGL((step_march<T, TY, false, false, true, MW>), grid, block, 0, p->stream, m); \
+  if (obj) hipLaunchKernelGGL((step_march<T, TY, false, true, false, MW>), grid, block, 0, p->stream, m);
+  else if (constants) hipLaunchKernelGGL((step_march<T, TY, false, false, true, MW>), grid, block, 0, p->stream, m);
   else hipLaunchKernelGGL((step_march<T, TY, false, false, false, MW>), grid, block, 0, p->stream, m);
-  if (waves <= 8) { MARCH(8) } else { MARCH(MARCH_MAX_WAVES) }
-#undef MARCH
   return 0;
+}
+
+// Rows per workgroup and workgroup size of the marching kernels.  float32: 4 rows.  float64:
+// 4 rows in workgroups of up to 8 waves (z rows of up to 512 cells: 160-168 registers, 3 waves
+// per SIMD; 512^3 vacuum 2.43 ms per step against 2.53 with 2 rows -- 1, 3, 6 and 8 rows:
+// 2.98, 2.92, 2.76, 2.74), 2 rows in the 16-wave workgroups of longer z rows, which may use
+// 128 registers and would spill with 4.  (float32 with 2, 3, 5, 6, 8 rows: 1.22, 1.45, 1.38,
+// 1.36, 1.18 against 1.19 ms with 4.)
+template <typename T>
+int launch_march(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
+  if ((p->nz + 63) / 64 <= 8)
+    return launch_march_tiles<T, sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : FDTDHIP_MARCH_TY64, 8>(p, a, obj);
+  return launch_march_tiles<T, sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : 2, MARCH_MAX_WAVES>(p, a, obj);
 }
 
 // The marching step of a plan with PML faces, objects or open slab faces, in pieces: E half
@@ -1370,9 +1383,8 @@ int launch_march(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
 enum { ST_E_FREE = 1, ST_MARCH_A = 2, ST_E_GHOST = 4, ST_MARCH_B = 8, ST_H_FREE = 16, ST_H_GHOST = 32,
        ST_ALL = 63 };
 
-template <typename T>
-int launch_march_shell(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, int stages) {
-  constexpr int TY = sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : 2;
+template <typename T, int TY, int MW>
+int launch_march_shell_tiles(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, int stages) {
   int c[6], hole[6];
   if (!march_core(p, c, hole)) return fail(-1, "internal: no core box for the marching step");
   const int nx = p->nx, ny = p->ny, nz = p->nz;
@@ -1468,13 +1480,10 @@ int launch_march_shell(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, int stag
       const dim3 grid(m.band ? 8 * m.band : tiles, count, 1), block(64 * waves);
       const bool constants = p->mat_const[0] && p->mat_const[1];
       if (int rc = span_begin(p, slot)) return rc;
-#define MARCH(MW)                                                                                     \
-  if (holed && constants) hipLaunchKernelGGL((step_march_box<T, TY, true, true, MW>), grid, block, 0, p->stream, m); \
-  else if (holed) hipLaunchKernelGGL((step_march_box<T, TY, true, false, MW>), grid, block, 0, p->stream, m); \
-  else if (constants) hipLaunchKernelGGL((step_march_box<T, TY, false, true, MW>), grid, block, 0, p->stream, m); \
-  else hipLaunchKernelGGL((step_march_box<T, TY, false, false, MW>), grid, block, 0, p->stream, m);
-      if (waves <= 8) { MARCH(8) } else { MARCH(MARCH_MAX_WAVES) }
-#undef MARCH
+      if (holed && constants) hipLaunchKernelGGL((step_march_box<T, TY, true, true, MW>), grid, block, 0, p->stream, m);
+      else if (holed) hipLaunchKernelGGL((step_march_box<T, TY, true, false, MW>), grid, block, 0, p->stream, m);
+      else if (constants) hipLaunchKernelGGL((step_march_box<T, TY, false, true, MW>), grid, block, 0, p->stream, m);
+      else hipLaunchKernelGGL((step_march_box<T, TY, false, false, MW>), grid, block, 0, p->stream, m);
       HIPCHK(hipGetLastError());
       if (int rc = span_end(p, slot, TIME_WHOLE)) return rc;
     }
@@ -1486,6 +1495,13 @@ int launch_march_shell(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, int stag
     if (int rc = shell_h(table({{h_hi, nx, 0, ny, 0, nz}}))) return rc;
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+template <typename T>
+int launch_march_shell(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, int stages) {
+  if ((p->nz + 63) / 64 <= 8)
+    return launch_march_shell_tiles<T, sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : FDTDHIP_MARCH_TY64, 8>(p, a, obj, stages);
+  return launch_march_shell_tiles<T, sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : 2, MARCH_MAX_WAVES>(p, a, obj, stages);
 }
 
 // Kernel arguments of a whole step at time index q (both half steps, the second buffers,

@@ -27,9 +27,12 @@
 // traces.  Per cell and step: (TY+2)/TY rows of H and (TY+1)/TY rows of E read, one row of
 // each written, times (LX+1)/LX for the reads.
 //
-// MI355X, 512^3 float32 vacuum, constants: 1.17 ms per step against 1.66 ms for two
-// half-step launches (TY = 4: 97 registers, 4 waves per SIMD; TY = 2: 1.26 ms, 3: 1.23,
-// 5: 1.32, 8: 1.40; chunks of 16 to 128 planes within 2 %, a single chunk 2.6 ms).
+// MI355X, 512^3 float32 vacuum, constants: 1.18 ms per step against 1.66 ms for two
+// half-step launches (TY = 4: 102 registers, 4 waves per SIMD; other tile heights: see
+// launch_march; chunks of 16 to 128 planes within 3 %, a single chunk 2.6 ms).  The rows and
+// planes that neighbouring tiles and chunks read twice meet in the L2 (tiles in bands per
+// XCD, plain loads): rocprofv3 counts 6.59 GB of traffic per step against 6.44 GB for every
+// value moved once (float64: 13.6 against 12.9).
 #pragma once
 
 #include "plan.hpp"
@@ -39,6 +42,18 @@
 namespace fdtdhip {
 
 constexpr int MARCH_MAX_WAVES = 16;   // z rows of up to 1024 cells
+
+// Results leave with non-temporal stores (nothing reads them before the next step); every
+// load is a plain one.  Non-temporal loads of E -- each row is needed once per tile -- were
+// the first choice and cost 7 % in float32 and 17 % in float64 (512^3 vacuum: 1.258 -> 1.18
+// and 3.03 -> 2.53 ms per step with plain loads): the row below a tile is the first row of
+// the next tile, and a line loaded non-temporally is gone from the L2 by the time that tile
+// asks for it.  (Non-temporal loads of the H rows no other tile reads: 1.28 ms, the z
+// neighbour's plain load of the same line follows at once; plain stores: 1.235 ms.)
+template <typename T>
+__device__ __forceinline__ void march_store(T v, T* o) {
+  __builtin_nontemporal_store(v, o);
+}
 
 template <typename T>
 struct MarchArgs {
@@ -122,9 +137,7 @@ __global__ __launch_bounds__(64 * MW) void step_march(MarchArgs<T> ma) {
         if (j < ny) {
           const int64_t c3 = pbase + (int64_t)j * sy;
           Hc[r][0] = H0[c3]; Hc[r][1] = H0[c3 + 1]; Hc[r][2] = H0[c3 + 2];
-          En[r][0] = __builtin_nontemporal_load(E0 + c3);
-          En[r][1] = __builtin_nontemporal_load(E0 + c3 + 1);
-          En[r][2] = __builtin_nontemporal_load(E0 + c3 + 2);
+          En[r][0] = E0[c3]; En[r][1] = E0[c3 + 1]; En[r][2] = E0[c3 + 2];
           const T* z = H0 + (hasz ? c3 - 3 : c3);
           zx[r] = z[0]; zy[r] = z[1];
         }
@@ -157,9 +170,9 @@ __global__ __launch_bounds__(64 * MW) void step_march(MarchArgs<T> ma) {
         if (a.nsrc > 0) march_sources<T>(a, c3, En[r]);
         if (owner) {
           T* o = a.E1 + c3;
-          __builtin_nontemporal_store(En[r][0], o);
-          __builtin_nontemporal_store(En[r][1], o + 1);
-          __builtin_nontemporal_store(En[r][2], o + 2);
+          march_store(En[r][0], o);
+          march_store(En[r][1], o + 1);
+          march_store(En[r][2], o + 2);
         }
       }
     }
@@ -188,9 +201,9 @@ __global__ __launch_bounds__(64 * MW) void step_march(MarchArgs<T> ma) {
           else cell_material<T, false, false>(a.h, c3, ih, j, k, m);
           finish_H<T, HAS_PML>(a.h, ih, j, k, d, h, m);
           T* o = a.H1 + c3;
-          __builtin_nontemporal_store(h[0], o);
-          __builtin_nontemporal_store(h[1], o + 1);
-          __builtin_nontemporal_store(h[2], o + 2);
+          march_store(h[0], o);
+          march_store(h[1], o + 1);
+          march_store(h[2], o + 2);
         }
       }
     }
@@ -281,9 +294,7 @@ __global__ __launch_bounds__(64 * MW) void step_march_box(MarchArgs<T> ma) {
           if (zhole && holed[r]) {
             En[r][0] = E1r[c3]; En[r][1] = E1r[c3 + 1]; En[r][2] = E1r[c3 + 2];
           } else {
-            En[r][0] = __builtin_nontemporal_load(E0 + c3);
-            En[r][1] = __builtin_nontemporal_load(E0 + c3 + 1);
-            En[r][2] = __builtin_nontemporal_load(E0 + c3 + 2);
+            En[r][0] = E0[c3]; En[r][1] = E0[c3 + 1]; En[r][2] = E0[c3 + 2];
             const T* z = H0 + (hasz ? c3 - 3 : c3);
             zx[r] = z[0]; zy[r] = z[1];
           }
@@ -323,9 +334,9 @@ __global__ __launch_bounds__(64 * MW) void step_march_box(MarchArgs<T> ma) {
           if (a.nsrc > 0) march_sources<T>(a, c3, En[r]);
           if (owner) {
             T* o = a.E1 + c3;
-            __builtin_nontemporal_store(En[r][0], o);
-            __builtin_nontemporal_store(En[r][1], o + 1);
-            __builtin_nontemporal_store(En[r][2], o + 2);
+            march_store(En[r][0], o);
+            march_store(En[r][1], o + 1);
+            march_store(En[r][2], o + 2);
           }
         }
       }
@@ -355,9 +366,9 @@ __global__ __launch_bounds__(64 * MW) void step_march_box(MarchArgs<T> ma) {
           else cell_material<T, false, false>(a.h, c3, ih, j, k, m);
           finish_H<T, false>(a.h, ih, j, k, d, h, m);
           T* o = a.H1 + c3;
-          __builtin_nontemporal_store(h[0], o);
-          __builtin_nontemporal_store(h[1], o + 1);
-          __builtin_nontemporal_store(h[2], o + 2);
+          march_store(h[0], o);
+          march_store(h[1], o + 1);
+          march_store(h[2], o + 2);
         }
       }
     }
