@@ -34,6 +34,9 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+const char* const kStaged =
+    "a step taken in stages (fdtdhip_step_stage) is in progress: finish it with the remaining stages first";
+
 const char* const kPoisoned =
     "an earlier fused step failed half way: the plan's state is split between its two buffer "
     "sets; call fdtdhip_plan_reset (and set the fields again) before stepping";
@@ -165,6 +168,8 @@ struct fdtdhip_plan {
   bool no_alloc = false;                    // inside fdtdhip_adjoint_run_noalloc: device tables
                                             // live in the static scratch array, nothing may
                                             // be allocated or freed
+  int stage_next = 0;                       // fdtdhip_step_stage: the piece of the step due next
+                                            // (0: no step in progress)
   bool poisoned = false;                    // a fused step failed while the state lived in the
                                             // second buffers: only reset / destroy are accepted
   std::vector<BoundaryRef> boundaries;
@@ -217,6 +222,7 @@ int release_tables(fdtdhip_plan* p) {
   p->pml_dirty = true;
   p->step_flipped = false;
   p->poisoned = false;
+  p->stage_next = 0;
   p->boundaries.clear();
   p->pmls.clear();
   p->objs.clear();
@@ -544,6 +550,7 @@ int scan_material(fdtdhip_plan* p, int w) {
 template <typename T>
 int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
   if (p->poisoned) return fail(-5, kPoisoned);
+  if (p->stage_next != 0) return fail(-1, kStaged);
   if (!p->E || !p->H || !p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
   if (x0 < 0 || x1 > p->nx || x0 > x1) return fail(-1, "bad x range");
   if (x0 == x1) return 0;
@@ -2144,6 +2151,7 @@ int fdtdhip_update_H(fdtdhip_plan* p, int64_t q) {
 
 int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
   if (!p) return fail(-1, "null plan");
+  if (p->stage_next != 0) return fail(-1, kStaged);
   int64_t s = 0;
   if (const FusedKind kind = fused_kind(p)) {
     // pairs of fused steps: first -> second buffers and back, so that the state ends
@@ -2188,6 +2196,9 @@ int fdtdhip_step_stage(fdtdhip_plan* p, int64_t q, int stage) {
   if (stage < 0 || stage > 3) return fail(-1, "stage is 0..3");
   GUARD(p);
   if (p->poisoned) return fail(-5, kPoisoned);
+  if (stage != p->stage_next)
+    return fail(-1, "fdtdhip_step_stage: stage " + std::to_string(p->stage_next) + " is due, not stage " +
+                        std::to_string(stage));
   if (stage == 0) {
     if (!p->E || !p->H || !p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
     if (fused_kind(p, true) != FUSED_MARCH)
@@ -2197,6 +2208,7 @@ int fdtdhip_step_stage(fdtdhip_plan* p, int64_t q, int stage) {
   const int rc = DISPATCH(p, staged_step<float>(p, q, stage), staged_step<double>(p, q, stage));
   // (memory variables are advanced in place: a step that stops half way cannot be repeated)
   if (rc) p->poisoned = true;
+  else p->stage_next = (stage + 1) % 4;
   return rc;
 }
 

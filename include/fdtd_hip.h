@@ -272,7 +272,9 @@ int fdtdhip_run(fdtdhip_plan* plan, int64_t q0, int64_t nsteps);
  *            swap (the second buffers hold the state, as after an odd number of fused
  *            steps inside fdtdhip_run) and the detectors are read.
  * Results equal fdtdhip_update_E + fdtdhip_update_H bit for bit.  Take steps in pairs so
- * that the state ends in the first buffers; a failed stage poisons the plan (reset it).
+ * that the state ends in the first buffers.  The stages are accepted in their order only, and
+ * while a step is in progress the other stepping calls (fdtdhip_update_*, fdtdhip_run) are
+ * refused; a failed stage poisons the plan (reset it).
  * fdtdhip_plan_whole_step_kind: which whole-step kernel the plan would take -- 0 none, 1 the
  * one-lane-per-cell kernel (small 2-D grids), 2 the marching kernel; `staged` != 0 asks for
  * fdtdhip_step_stage (open slab faces allowed).  core / hole (may be NULL) receive the box

@@ -4,6 +4,7 @@ without a GPU.  No compute calls (CPU-only suite)."""
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 
@@ -36,6 +37,9 @@ def test_argument_errors_are_reported_not_crashed():
     rc = lib.fdtdhip_plan_create(ctypes.byref(handle), 4, 4, 4, 7, 0.5, 0)
     assert rc < 0 and b"dtype" in lib.fdtdhip_last_error()
     assert lib.fdtdhip_update_E(None, 0) < 0
+    assert lib.fdtdhip_step_stage(None, 0, 0) < 0
+    assert lib.fdtdhip_plan_whole_step_kind(None, 1, None, None) < 0
+    assert lib.fdtdhip_plan_get_timing_parts(None, None, None) < 0
     with pytest.raises(_lib.NativeError):
         _lib.check(lib.fdtdhip_run(None, 0, 1))
 
@@ -131,6 +135,10 @@ def test_bad_arguments_on_a_live_plan_return_errors():
         refused("step without detector output", lib.fdtdhip_update_E(h, 0))
         refused("output of an unknown detector", lib.fdtdhip_plan_set_detector_output(h, det + 3, None, None, 4))
         refused("adjoint with a null array", lib.fdtdhip_adjoint_run(h, 2, None, p(H), p(E)))
+        refused("stage out of range", lib.fdtdhip_step_stage(h, 0, 4))
+        refused("stage out of order", lib.fdtdhip_step_stage(h, 0, 2))
+        refused("staged step without second buffers", lib.fdtdhip_step_stage(h, 0, 0))
+        assert lib.fdtdhip_plan_whole_step_kind(h, 1, None, None) == 0    # no whole-step kernel for this plan
         assert not accepted, f"accepted instead of refused: {accepted}"
         assert lib.fdtdhip_last_error()                                                    # a message is kept
         # and the plan still works after all of that
@@ -141,3 +149,65 @@ def test_bad_arguments_on_a_live_plan_return_errors():
         assert float(E.abs().max()) == 0.0
     finally:
         assert lib.fdtdhip_plan_destroy(h) == 0
+
+
+_STAGED = r"""
+import ctypes, sys
+import torch
+sys.path.insert(0, %r)
+from fdtd_amd import _lib
+lib = _lib.load()
+p = lambda t: ctypes.c_void_p(t.data_ptr())
+gen = torch.Generator(device="cuda").manual_seed(5)
+rnd = lambda *s: torch.rand(*s, dtype=torch.float64, device="cuda", generator=gen) - 0.5
+shape = (12, 9, 70)
+E0, H0 = rnd(*shape, 3), rnd(*shape, 3)
+below, above = rnd(shape[1], shape[2], 2), rnd(shape[1], shape[2], 2)
+ie, im = torch.full((*shape, 3), 0.8, dtype=torch.float64, device="cuda"), torch.ones(*shape, 3, dtype=torch.float64, device="cuda")
+results = []
+for staged in (False, True):
+    h = ctypes.c_void_p()
+    assert lib.fdtdhip_plan_create(ctypes.byref(h), *shape, _lib.F64, 0.5, 0) == 0
+    E, H = E0.clone(), H0.clone()
+    E1, H1 = torch.empty_like(E), torch.empty_like(H)
+    assert lib.fdtdhip_plan_set_fields(h, p(E), p(H), p(ie), p(im)) == 0
+    assert lib.fdtdhip_plan_set_halo(h, p(below), p(above)) == 0
+    assert lib.fdtdhip_plan_scan_materials(h, 1) == 3
+    if staged:
+        assert lib.fdtdhip_plan_set_step_buffers(h, p(E1), p(H1)) == 0
+        core = (ctypes.c_int32 * 6)()
+        assert lib.fdtdhip_plan_whole_step_kind(h, 1, core, None) == 2, lib.fdtdhip_last_error()
+        assert list(core) == [1, 11, 0, 9, 0, 70], list(core)
+        assert lib.fdtdhip_plan_whole_step_kind(h, 0, None, None) == 0      # open faces: not inside fdtdhip_run
+        assert lib.fdtdhip_step_stage(h, 0, 1) < 0                           # stage 0 is due
+        assert lib.fdtdhip_step_stage(h, 0, 0) == 0, lib.fdtdhip_last_error()
+        assert lib.fdtdhip_run(h, 0, 2) < 0 and b"in progress" in lib.fdtdhip_last_error()
+        assert lib.fdtdhip_update_E(h, 0) < 0
+        assert lib.fdtdhip_step_stage(h, 0, 2) < 0 and b"stage 1 is due" in lib.fdtdhip_last_error()
+        for stage in (1, 2, 3):
+            assert lib.fdtdhip_step_stage(h, 0, stage) == 0, lib.fdtdhip_last_error()
+        for stage in range(4):                                               # back into the first buffers
+            assert lib.fdtdhip_step_stage(h, 1, stage) == 0, lib.fdtdhip_last_error()
+    else:
+        for q in range(2):
+            assert lib.fdtdhip_update_E(h, q) == 0 and lib.fdtdhip_update_H(h, q) == 0
+    torch.cuda.synchronize()
+    results.append((E.clone(), H.clone()))
+    assert lib.fdtdhip_plan_destroy(h) == 0
+assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+assert not torch.equal(results[0][0], E0)
+print("staged ok")
+"""
+
+
+@pytest.mark.gpu
+def test_whole_steps_in_stages_through_the_c_abi():
+    """fdtdhip_step_stage on a slab with both x faces open, driven through ctypes alone: the
+    order of the stages is enforced, other stepping calls are refused while a step is in
+    progress, and two staged steps equal two pairs of half steps bit for bit (the ghost planes
+    held fixed).  FDTDHIP_FUSED=2 lets a grid this small take the marching kernel."""
+    import subprocess
+
+    done = subprocess.run([sys.executable, "-c", _STAGED % ROOT], env=dict(os.environ, FDTDHIP_FUSED="2"),
+                          capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0 and "staged ok" in done.stdout, done.stdout[-2000:] + done.stderr[-3000:]
