@@ -34,7 +34,7 @@ Extra objects in the JSON line:
                 timed on this machine's host cores on bounded samples (128^3 and 256^3)
   also          (one GPU, default workload, unless --no-also) the other benchmark
                 configurations measured by the same run: the headline grid with both material
-                arrays read, the headline grid over 1000 steps ("sustained"), m3, m2, m3v64
+                arrays read, the headline grid over 1000 steps ("sustained"), m3, m2, m3v64, m4
 """
 
 import argparse
@@ -486,6 +486,7 @@ def main():
         also["m3_array_materials"] = measure_single("m3", 100, 10, "arrays")
         also["m2"] = measure_single("m2", 1000, 20)
         also["m3v64"] = measure_single("m3v64", 100, 10)
+        also["m4"] = measure_single("m4", 100, 10)     # one GPU's share of the 8-GPU configuration
         out["also"] = also
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
