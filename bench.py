@@ -77,7 +77,8 @@ def build_workload(fdtd, name, n_slabs=1, rank=0, group=None):
     if n_slabs > 1:
         from fdtd_amd.parallel import SlabGrid
 
-        grid = SlabGrid((shape[0] * n_slabs, shape[1], shape[2]), group=group)
+        grid = SlabGrid((shape[0] * n_slabs, shape[1], shape[2]), group=group,
+                        planes=slab_planes(name, shape[0], n_slabs))
     else:
         grid = fdtd.Grid(shape)
     nx, ny, nz = grid.Nx_global, grid.Ny, grid.Nz  # extents of the whole simulation
@@ -128,6 +129,25 @@ def build_workload(fdtd, name, n_slabs=1, rank=0, group=None):
             f.uniform_(-1e-3, 1e-3, generator=gen)
     cells = shape[0] * shape[1] * shape[2]
     return grid, cells, es, dt, desc
+
+
+def slab_planes(name, per_rank, n_slabs):
+    """x planes of every rank.  The two end slabs of a simulation with PMLs on its x faces
+    carry ten planes of PML cells each, which cost more than plain ones (measured on one GPU,
+    tools/slab_step_cost.py: the first slab of m4 2.95 ms per step against 2.84 ms for an
+    interior one, i.e. 9.6 planes' worth): with three or more ranks the end slabs hand
+    9.6 (n - 2) / n planes each to the interior ones (seven on eight ranks), so that every
+    rank's step takes about the same time.  The simulation and its total number of cells stay
+    what they are."""
+    if name != "m4" or n_slabs < 3:
+        return None
+    trim = round(9.6 * (n_slabs - 2) / n_slabs)
+    planes = [per_rank] * n_slabs
+    planes[0] -= trim
+    planes[-1] -= trim
+    for n in range(2 * trim):
+        planes[1 + n % (n_slabs - 2)] += 1
+    return planes
 
 
 def half_step_bytes(grid, cells, es, mask):
@@ -459,7 +479,8 @@ def main():
     out = None
     if rank == 0:
         value = cells * world * args.steps / elapsed / 1e9
-        roof = roofline(grid, cells, es, timing, mask, args.steps, workload)
+        # (this rank's own cells: the slabs of a run may differ in thickness)
+        roof = roofline(grid, grid.Nx * grid.Ny * grid.Nz, es, timing, mask, args.steps, workload)
         roof["launches"] = sum(timing["n"])
         out = {
             "metric": "Yee cell-updates/s", "value": round(value, 3), "unit": "Gcells/s",
@@ -470,7 +491,9 @@ def main():
                        "parallelism": f"x-slab x{world}" if world > 1 else "single GPU",
                        "cells_per_gpu": cells,
                        **({"transport": transport,
-                           "halo": f"{grid.Ny}x{grid.Nz}x2 {dt} per half step and neighbour"} if transport else {})},
+                           "halo": f"{grid.Ny}x{grid.Nz}x2 {dt} per half step and neighbour",
+                           "planes_per_rank": slab_planes(workload, cells // (grid.Ny * grid.Nz), world)
+                                              or "even"} if transport else {})},
             "roofline": roof,
         }
         if one_slab is not None:

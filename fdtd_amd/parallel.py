@@ -114,9 +114,13 @@ class SlabGrid(Grid):
     ("nccl", i.e. RCCL, for GPUs)."""
 
     def __init__(self, shape, grid_spacing=155e-9, permittivity=1.0, permeability=1.0,
-                 courant_number=None, group=None, engine_factory=None):
+                 courant_number=None, group=None, engine_factory=None, planes=None):
         if not dist.is_initialized():
             raise RuntimeError("SlabGrid needs torch.distributed.init_process_group first")
+        # planes: x planes of every rank, in rank order (the same list on every rank), for
+        # slabs of unequal cost -- e.g. fewer planes for the two end slabs, which carry the
+        # PMLs on the x faces of the simulation; None: as even as possible
+        self._planes = None if planes is None else [int(n) for n in planes]
         self._group = group
         self._rank = dist.get_rank(group)
         self._world = dist.get_world_size(group)
@@ -132,17 +136,27 @@ class SlabGrid(Grid):
         self.whole_steps_taken = 0    # steps advanced by the whole-step kernel (diagnostics)
 
     # ------------------------------------------------------------ decomposition
-    def _partition(self):
-        n, p, r = self.Nx_global, self._world, self._rank
+    def _plane_counts(self):
+        """x planes of every rank, in rank order."""
+        n, p = self.Nx_global, self._world
+        if self._planes is not None:
+            if len(self._planes) != p or sum(self._planes) != n or min(self._planes) < 1:
+                raise ValueError(f"planes={self._planes} does not deal {n} x planes to {p} ranks "
+                                 "(one entry per rank, each at least 1)")
+            return list(self._planes)
         if n < p:
             raise ValueError(f"cannot split {n} x planes over {p} ranks")
         base, extra = divmod(n, p)
-        self.Nx = base + (1 if r < extra else 0)
-        self.x_offset = r * base + min(r, extra)
+        return [base + (1 if r < extra else 0) for r in range(p)]
+
+    def _partition(self):
+        counts = self._plane_counts()
+        self.Nx = counts[self._rank]
+        self.x_offset = sum(counts[:self._rank])
 
     def _planes_of_end_slab(self, side):
-        base, extra = divmod(self.Nx_global, self._world)
-        return base + (1 if side == "low" and extra > 0 else 0)
+        counts = self._plane_counts()
+        return counts[0] if side == "low" else counts[-1]
 
     def _global_rank(self, r):
         return r if self._group is None else dist.get_global_rank(self._group, r)
@@ -177,8 +191,8 @@ class SlabGrid(Grid):
         as that rank leaves it at the end of the H half step.  The same answer on every rank."""
         if self._world == 1:
             return False
-        base, extra = divmod(self.Nx_global, self._world)
-        firsts = {r * base + min(r, extra) for r in range(self._world)}
+        counts = self._plane_counts()
+        firsts = {sum(counts[:r]) for r in range(self._world)}
         return any(getattr(d, "_kind", None) == _lib.DET_CURRENT
                    and any(self._cell_index(x, self.Nx_global) in firsts for x in d.x)
                    for d in self.detectors)

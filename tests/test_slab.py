@@ -23,7 +23,7 @@ import scenes  # noqa: E402
 import slab_support  # noqa: E402
 
 
-def _worker(rank, world, port, scene_name, on_gpu, out):
+def _worker(rank, world, port, scene_name, on_gpu, out, planes=None):
     import torch.distributed as dist
 
     import fdtd_amd as fdtd
@@ -39,7 +39,9 @@ def _worker(rank, world, port, scene_name, on_gpu, out):
             factory = slab_support.OracleSlabEngine
         scene = scenes.SLAB_SCENES[scene_name]
         grid, made = scenes.build_api(
-            scene, fdtd, grid_factory=lambda **kw: SlabGrid(engine_factory=factory, **kw))
+            scene, fdtd, grid_factory=lambda **kw: SlabGrid(engine_factory=factory, planes=planes, **kw))
+        if planes is not None:
+            assert grid.Nx == planes[rank] and grid.x_offset == sum(planes[:rank])
         half = scene["steps"] // 2
         grid.run(half)
         for _ in range(scene["steps"] - half):  # the half-step entry points too
@@ -73,10 +75,10 @@ def _single_grid_oracle(scene):
     return og, omade
 
 
-def _check(scene_name, world, on_gpu, tmp_path):
+def _check(scene_name, world, on_gpu, tmp_path, planes=None):
     out = str(tmp_path / f"{scene_name}_{world}.npz")
     port = slab_support.free_port()
-    mp.spawn(_worker, args=(world, port, scene_name, on_gpu, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, scene_name, on_gpu, out, planes), nprocs=world, join=True)
     z = np.load(out)
     scene = scenes.SLAB_SCENES[scene_name]
     og, omade = _single_grid_oracle(scene)
@@ -102,6 +104,46 @@ def test_five_slabs_cpu(tmp_path):
     """More ranks than any component is wide: interior ranks with two neighbours, x-PMLs
     that end inside the first and last slab, objects and line sources cut several times."""
     _check("slab_mix", 5, False, tmp_path)
+
+
+def test_slabs_of_unequal_thickness_cpu(tmp_path):
+    """planes=[...]: the caller deals the x planes to the ranks (thin end slabs that just
+    hold their PMLs, a thick one in the middle; detector points and the objects cut at
+    other planes than the even split would)."""
+    _check("slab_mix", 3, False, tmp_path, planes=[4, 19, 3])
+    _check("slab_2d", 4, False, tmp_path, planes=[5, 12, 9, 5])
+
+
+def _bad_planes_worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    import fdtd_amd as fdtd
+    from fdtd_amd.parallel import SlabGrid
+
+    slab_support.init_gloo(rank, world, port)
+    try:
+        fdtd.set_backend("hip.float64", device="host-staging")
+        refused = 0
+        for planes in ([5, 5], [3, 0, 7], [4, 4, 4]):
+            try:
+                SlabGrid((10, 4, 4), planes=planes, engine_factory=slab_support.OracleSlabEngine)
+            except ValueError:
+                refused += 1
+        if rank == 0:
+            open(out, "w").write(str(refused))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_partition_that_does_not_cover_the_grid_is_refused(tmp_path):
+    out = str(tmp_path / "bad_planes.txt")
+    mp.spawn(_bad_planes_worker, args=(3, slab_support.free_port(), out), nprocs=3, join=True)
+    assert open(out).read() == "3"
+
+
+@pytest.mark.gpu
+def test_slabs_of_unequal_thickness_gpu(tmp_path):
+    _check("slab_mix", 3, True, tmp_path, planes=[4, 19, 3])
 
 
 @pytest.mark.gpu
@@ -247,8 +289,8 @@ def test_partition_arithmetic():
     from fdtd_amd.parallel import SlabGrid
 
     class Fake(SlabGrid):
-        def __init__(self, n, world, rank):
-            self.Nx_global, self._world, self._rank = n, world, rank
+        def __init__(self, n, world, rank, planes=None):
+            self.Nx_global, self._world, self._rank, self._planes = n, world, rank, planes
             self._partition()
 
     for n, world in ((26, 2), (26, 3), (512, 8), (9, 4), (4, 4)):
@@ -258,6 +300,9 @@ def test_partition_arithmetic():
         assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
     with pytest.raises(ValueError):
         Fake(3, 4, 0)
+    given = [Fake(20, 3, r, [2, 15, 3]) for r in range(3)]
+    assert [(f.x_offset, f.Nx) for f in given] == [(0, 2), (2, 15), (17, 3)]
+    assert given[1]._planes_of_end_slab("low") == 2 and given[1]._planes_of_end_slab("high") == 3
 
 
 def _refusal_worker(rank, world, port, out):

@@ -6,7 +6,8 @@ synchronisation cost on one device -- no xGMI, but every launch, wait and copy o
 schedule.  FDTDHIP_FUSED=0 in the environment: two half-step launches per step (with the
 interior / boundary-plane split); default: whole steps in stages.
 
-    python tools/slab_step_cost.py [steps] [workload: m4 | m3v]
+    python tools/slab_step_cost.py [steps] [workload: m4 | m4end (the first slab: a PML on its
+                                                     low x face, one neighbour) | m3v]
 """
 import os
 import sys
@@ -28,13 +29,23 @@ from fdtd_amd.parallel import SlabGrid  # noqa: E402
 class InteriorSlab(SlabGrid):
     """A slab that believes it is rank 1 of 3 and exchanges planes with itself."""
 
-    def __init__(self, shape):
+    def __init__(self, shape, first=False):
         super().__init__(shape)
-        self._rank, self._world = 1, 3
+        self._rank, self._world = (0 if first else 1), 3
         plane = (self.Ny, self.Nz, 2)
-        self._H_below, self._E_above = bd.zeros(plane), bd.zeros(plane)
+        self._H_below, self._E_above = (None if first else bd.zeros(plane)), bd.zeros(plane)
         self._halo = (self._H_below, self._E_above)
-        self._send_H, self._send_E = bd.zeros(plane), bd.zeros(plane)
+        self._send_H, self._send_E = bd.zeros(plane), (None if first else bd.zeros(plane))
+
+    def _start_exchange(self, send, dst, recv, src):
+        # (the first slab of a chain sends H up and receives E from above: with itself as the
+        # only peer both directions have to exist, so it sends into a spare plane)
+        if self._rank == 0 and (send is None) != (recv is None):
+            if recv is None:
+                recv = self._spare = getattr(self, "_spare", None) if getattr(self, "_spare", None) is not None else bd.zeros(send.shape)
+            else:
+                send = self._spare = getattr(self, "_spare", None) if getattr(self, "_spare", None) is not None else bd.zeros(recv.shape)
+        return super()._start_exchange(send, dst, recv, src)
 
     def _global_rank(self, r):
         return 0
@@ -47,9 +58,11 @@ class InteriorSlab(SlabGrid):
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 workload = sys.argv[2] if len(sys.argv) > 2 else "m4"
 fdtd.set_backend("hip.float32", device=0)
-shape = (256, 1024, 1024) if workload == "m4" else (512, 512, 512)
-g = InteriorSlab(shape)
-if workload == "m4":
+shape = (256, 1024, 1024) if workload in ("m4", "m4end") else (512, 512, 512)
+g = InteriorSlab(shape, first=workload == "m4end")
+if workload == "m4end":      # the first slab of the chain: the low x face of the simulation
+    g[0:10, :, :] = fdtd.PML()
+if workload in ("m4", "m4end"):
     for key in ((slice(None), slice(0, 10)), (slice(None), slice(-10, None)),
                 (slice(None), slice(None), slice(0, 10)), (slice(None), slice(None), slice(-10, None))):
         g[key] = fdtd.PML()
