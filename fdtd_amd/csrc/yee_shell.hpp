@@ -66,10 +66,14 @@ struct ShellSources {
   int64_t elem[MAX_STEP_SOURCES];
   T value[MAX_STEP_SOURCES];
 };
+// One lane adds them one after the other, in the order of the plan's sources: two sources may
+// sit on the same cell, and the reference's sums are sequential.
 template <typename T>
 __global__ void shell_sources(T* E1, ShellSources<T> s) {
-  const int t = threadIdx.x;
-  if (t < s.n) E1[s.elem[t]] += s.value[t];
+  if (threadIdx.x != 0) return;
+#pragma unroll
+  for (int n = 0; n < MAX_STEP_SOURCES; ++n)
+    if (n < s.n) E1[s.elem[n]] += s.value[n];
 }
 
 // E half step of the cells of `b`: a.F (read) -> out.  The arithmetic of bulk_E_generic.

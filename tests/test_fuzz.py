@@ -506,3 +506,31 @@ def test_reused_grid_training_loop_equals_fresh_grids():
             bad[f"substrate{seed}"] = out
     assert not bad, bad
 
+
+
+@pytest.mark.gpu
+def test_random_scenes_with_the_marching_step_forced():
+    """FDTDHIP_FUSED=2 gives every plan that can take it the marching whole-step kernel with
+    half steps over the shell of PML faces and objects -- also 1-D and 2-D grids, grids of a
+    few cells, cores of one cell.  Seeds 20056, 21109, 21124 and 24000 hold two sources on one
+    cell of the shell (their additions once raced in the kernel that adds the shell's source
+    points).  The switch is read once per process, hence the child."""
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (f"import sys\nsys.path[:0] = [{os.path.dirname(here)!r}, {here!r}]\n"
+            "import test_fuzz as t\n"
+            "bad = {}\n"
+            "cases = [(s, 'float64', {}) for s in [20056] + list(range(20100, 20160))]\n"
+            "cases += [(s, 'float32', {}) for s in [21109, 21124] + list(range(21200, 21230))]\n"
+            "cases += [(s, 'float64', {'crowded': True}) for s in range(24000, 24012)]\n"
+            "cases += [(s, 'float64', {'big': True}) for s in range(22100, 22108)]\n"
+            "for seed, dtype, kw in cases:\n"
+            "    out = t.check_scene(seed, dtype, **kw)\n"
+            "    if out is not None and out[0]:\n"
+            "        bad[seed] = out[0]\n"
+            "assert not bad, bad\n"
+            "print('marched', len(cases), 'scenes')\n")
+    done = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FDTDHIP_FUSED="2"),
+                          capture_output=True, text=True, timeout=280, cwd=here)
+    assert done.returncode == 0 and "marched" in done.stdout, done.stdout[-2000:] + done.stderr[-3000:]
