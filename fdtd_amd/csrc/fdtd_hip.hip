@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <utility>
 #include <set>
 #include <string>
 #include <vector>
@@ -1277,6 +1279,8 @@ FusedKind fused_kind(const fdtdhip_plan* p, bool staged = false) {
   if (!(p->mat_const[0] && p->mat_const[1]) && !(p->pmls.empty() && p->objs.empty())) return FUSED_NONE;
   // (PML faces and objects: the shell and the box of the objects take half steps of their
   // own at a third of the marching kernel's rate per cell -- worth it while they are few)
+  // (256^3 with six ten-cell faces, 22 % of the cells: float64 0.489 against 0.508 ms per step
+  // in a bare loop and no difference in the benchmark, float32 0.256 against 0.235)
   if (march_ok && p->nz >= 128 && p->ny >= 64 && p->nx >= 64 && p->cells() >= (1ll << 22) &&
       shell_cells * MARCH_SHELL_SHARE <= p->cells())
     return FUSED_MARCH;
@@ -1325,6 +1329,52 @@ int build_detmap(fdtdhip_plan* p) {
   return 0;
 }
 
+// Workgroups of `kernel` (blocks of `threads`) that the GPU of the plan holds at once.
+int march_slots(fdtdhip_plan* p, const void* kernel, int threads) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> per_cu;
+  static std::map<int, int> cus;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_pair(kernel, threads);
+  if (!per_cu.count(key)) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess || n < 1) n = 2;
+    per_cu[key] = n;
+  }
+  if (!cus.count(p->device)) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || n < 1) n = 256;
+    cus[p->device] = n;
+  }
+  return per_cu[key] * cus[p->device];
+}
+
+// Planes per chunk of the marching kernels.  A workgroup takes one tile of rows through one
+// chunk of planes; all of them should keep the machine busy in whole rounds: 960 workgroups on
+// 768 places (256^3 float64 with six faces) left three quarters of the CUs idle for a fifth of
+// the launch (340 -> 323 us).  Among the chunk lengths of 16 to 128 planes the one with the
+// fullest rounds wins, counting the plane every chunk evaluates past its end, and a single
+// round counting 3 % less than several (512^3 float32: 4 chunks of 128 planes in one round
+// 1.215 ms, 8 chunks of 64 in two rounds 1.183).
+int march_chunk_planes(int planes, int tiles, int slots) {
+  static const int forced_lx = [] {
+    const char* e = getenv("FDTDHIP_MARCH_LX");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced_lx > 0) return forced_lx;
+  int best_lx = std::min(planes, 128);
+  double best = -1;
+  for (int chunks = 1; chunks <= std::max(1, planes / 16); ++chunks) {
+    const int lx = (planes + chunks - 1) / chunks;
+    if (lx > 128) continue;
+    const int64_t wgs = (int64_t)tiles * ((planes + lx - 1) / lx);
+    const int64_t rounds = (wgs + slots - 1) / slots;
+    const double score = (double)wgs / (double)(rounds * slots) * lx / (lx + 1.0) * (rounds >= 2 ? 1.0 : 0.97);
+    if (score > best + 1e-9) { best = score; best_lx = lx; }
+  }
+  return std::max(best_lx, 1);
+}
+
 // The marching step (yee_march.hpp) over the whole grid: plans without PMLs, objects and
 // open slab faces.  (The kernel carries no PML code: with the face code evaluated row after
 // row every workgroup waited, plane by plane, for its two waves on the z faces to walk their
@@ -1337,15 +1387,14 @@ int launch_march_tiles(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
   m.s = a;
   m.chunk0 = 0;
   const int tiles = (p->ny + TY - 1) / TY;
-  // chunks of planes short enough for about four workgroups per CU, 16 planes at least
-  int lx = (int)std::min<int64_t>(128, std::max<int64_t>(16, (int64_t)p->nx * tiles / 1024));
-  static const int forced_lx = [] {
-    const char* e = getenv("FDTDHIP_MARCH_LX");
-    return e ? atoi(e) : 0;
-  }();
-  if (forced_lx > 0) lx = forced_lx;
-  m.lx = lx;
   const int waves = (p->nz + 63) / 64;
+  const bool constants = p->mat_const[0] && p->mat_const[1];
+  // (a kernel limited to 8 waves per workgroup may use 256 registers, one for z rows of up to
+  // 1024 cells 128)
+  void (*kernel)(MarchArgs<T>) = obj ? step_march<T, TY, false, true, false, MW>
+                                 : constants ? step_march<T, TY, false, false, true, MW>
+                                             : step_march<T, TY, false, false, false, MW>;
+  const int lx = m.lx = march_chunk_planes(p->nx, tiles, march_slots(p, (const void*)kernel, 64 * waves));
   // tiles dealt to the XCDs in bands (see step_march); FDTDHIP_MARCH_BAND=0: plain order
   static const bool banded = [] {
     const char* e = getenv("FDTDHIP_MARCH_BAND");
@@ -1353,12 +1402,7 @@ int launch_march_tiles(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
   }();
   m.band = banded && tiles >= 16 ? (tiles + 7) / 8 : 0;
   const dim3 grid(m.band ? 8 * m.band : tiles, (p->nx + lx - 1) / lx, 1), block(64 * waves);
-  const bool constants = p->mat_const[0] && p->mat_const[1];
-  // (a kernel limited to 8 waves per workgroup may use 256 registers, one for z rows of up to
-  // 1024 cells 128)
-  if (obj) hipLaunchKernelGGL((step_march<T, TY, false, true, false, MW>), grid, block, 0, p->stream, m);
-  else if (constants) hipLaunchKernelGGL((step_march<T, TY, false, false, true, MW>), grid, block, 0, p->stream, m);
-  else hipLaunchKernelGGL((step_march<T, TY, false, false, false, MW>), grid, block, 0, p->stream, m);
+  hipLaunchKernelGGL(kernel, grid, block, 0, p->stream, m);
   return 0;
 }
 
@@ -1474,23 +1518,24 @@ int launch_march_shell_tiles(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, in
     for (int n = 0; n < 6; ++n) { m.box[n] = c[n]; m.hole[n] = hole[n]; }
     const bool holed = hole[1] > hole[0];
     const int tiles = (c[3] - c[2] + TY - 1) / TY, planes = c[1] - c[0];
-    // chunks of planes: as many as give two rounds of two workgroups per CU, not a few more
-    const int chunks = std::max(1, 1024 / tiles);
-    const int lx = m.lx = std::min(128, std::max(16, (planes + chunks - 1) / chunks));
-    const int nchunks = (planes + lx - 1) / lx, half = nchunks / 2;
     const int waves = (nz + 63) / 64;
-    m.band = tiles >= 16 ? (tiles + 7) / 8 : 0;
+    const bool constants = p->mat_const[0] && p->mat_const[1];
+    void (*kernel)(MarchArgs<T>) = holed ? (constants ? step_march_box<T, TY, true, true, MW>
+                                                      : step_march_box<T, TY, true, false, MW>)
+                                         : (constants ? step_march_box<T, TY, false, true, MW>
+                                                      : step_march_box<T, TY, false, false, MW>);
     const bool both = (stages & ST_MARCH_A) && (stages & ST_MARCH_B);
+    // (in two launches: each half of the planes should fill its rounds)
+    const int lx = m.lx = march_chunk_planes(both ? planes : (planes + 1) / 2, tiles,
+                                             march_slots(p, (const void*)kernel, 64 * waves));
+    const int nchunks = (planes + lx - 1) / lx, half = nchunks / 2;
+    m.band = tiles >= 16 ? (tiles + 7) / 8 : 0;
     m.chunk0 = both || (stages & ST_MARCH_A) ? 0 : half;
     const int count = both ? nchunks : ((stages & ST_MARCH_A) ? half : nchunks - half);
     if (count > 0) {
       const dim3 grid(m.band ? 8 * m.band : tiles, count, 1), block(64 * waves);
-      const bool constants = p->mat_const[0] && p->mat_const[1];
       if (int rc = span_begin(p, slot)) return rc;
-      if (holed && constants) hipLaunchKernelGGL((step_march_box<T, TY, true, true, MW>), grid, block, 0, p->stream, m);
-      else if (holed) hipLaunchKernelGGL((step_march_box<T, TY, true, false, MW>), grid, block, 0, p->stream, m);
-      else if (constants) hipLaunchKernelGGL((step_march_box<T, TY, false, true, MW>), grid, block, 0, p->stream, m);
-      else hipLaunchKernelGGL((step_march_box<T, TY, false, false, MW>), grid, block, 0, p->stream, m);
+      hipLaunchKernelGGL(kernel, grid, block, 0, p->stream, m);
       HIPCHK(hipGetLastError());
       if (int rc = span_end(p, slot, TIME_WHOLE)) return rc;
     }
