@@ -285,6 +285,30 @@ def test_rccl_point_to_point_on_one_gpu():
     assert "RCCL self send/recv of a plane: ok" in done.stdout
 
 
+@pytest.mark.gpu
+def test_staged_steps_over_rccl_equal_half_steps_bitwise():
+    """The real transport on the one GPU of the box: a slab with both x faces open that is
+    its own neighbour (a one-rank RCCL group sending the planes to itself, tools/
+    slab_step_cost.py), advanced by whole steps in stages and, in a second process, by half
+    steps.  RCCL's send / recv run on its own stream, ordered against the compute stream only
+    by the waits of the schedule: a stage that read a ghost plane before it arrived, or a plane
+    packed before its kernel finished, would change the checksum of the final state."""
+    import subprocess
+
+    tool = os.path.join(os.path.dirname(HERE), "tools", "slab_step_cost.py")
+    sums = {}
+    for mode, env in (("staged", {}), ("half steps", {"FDTDHIP_FUSED": "0"})):
+        port = str(slab_support.free_port())
+        done = subprocess.run([sys.executable, tool, "21", "small"], capture_output=True, text=True, timeout=280,
+                              env=dict(os.environ, MASTER_PORT=port, **env))
+        assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-3000:]
+        line = [ln for ln in done.stdout.splitlines() if ln.startswith("state checksum")][0]
+        taken = int(done.stdout.split("whole steps taken")[1].split()[0])
+        assert (taken > 0) == (mode == "staged"), done.stdout[-500:]
+        sums[mode] = line
+    assert sums["staged"] == sums["half steps"], sums
+
+
 def test_partition_arithmetic():
     from fdtd_amd.parallel import SlabGrid
 

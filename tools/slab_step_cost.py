@@ -7,7 +7,7 @@ schedule.  FDTDHIP_FUSED=0 in the environment: two half-step launches per step (
 interior / boundary-plane split); default: whole steps in stages.
 
     python tools/slab_step_cost.py [steps] [workload: m4 | m4end (the first slab: a PML on its
-                                                     low x face, one neighbour) | m3v]
+                                                     low x face, one neighbour) | m3v | small]
 """
 import os
 import sys
@@ -58,8 +58,12 @@ class InteriorSlab(SlabGrid):
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 workload = sys.argv[2] if len(sys.argv) > 2 else "m4"
 fdtd.set_backend("hip.float32", device=0)
-shape = (256, 1024, 1024) if workload in ("m4", "m4end") else (512, 512, 512)
+shape = {"m4": (256, 1024, 1024), "m4end": (256, 1024, 1024), "small": (64, 128, 512)}.get(workload, (512, 512, 512))
 g = InteriorSlab(shape, first=workload == "m4end")
+if workload == "small":      # the smallest slab the default policy marches, thin PMLs (tests)
+    for key in ((slice(None), slice(0, 4)), (slice(None), slice(-4, None)),
+                (slice(None), slice(None), slice(0, 4)), (slice(None), slice(None), slice(-4, None))):
+        g[key] = fdtd.PML()
 if workload == "m4end":      # the first slab of the chain: the low x face of the simulation
     g[0:10, :, :] = fdtd.PML()
 if workload in ("m4", "m4end"):
@@ -79,6 +83,10 @@ with torch.no_grad():
     torch.cuda.synchronize()
     t2 = time.perf_counter()
 cells = shape[0] * shape[1] * shape[2]
+# a checksum of the state's bit patterns: the same for both ways of stepping, or the schedule of
+# one of them reads a ghost plane too early / sends a plane too late
+bits = int(g.E.view(torch.int32).to(torch.int64).sum()) ^ (int(g.H.view(torch.int32).to(torch.int64).sum()) << 1)
+print(f"state checksum {bits:#x}, max|E| {float(g.E.abs().max()):.6e}")
 print(f"{workload} interior slab, FDTDHIP_FUSED={os.environ.get('FDTDHIP_FUSED', 'default')}: "
       f"{(t2 - t0) / steps * 1e3:.3f} ms/step = {cells * steps / (t2 - t0) / 1e9:.1f} Gcells/s, "
       f"host enqueue {(t1 - t0) / steps * 1e3:.3f} ms/step, whole steps taken {g.whole_steps_taken}",
