@@ -495,11 +495,16 @@ void fill_core(const fdtdhip_plan* p, BulkArgs<T>& a) {
       h[2 * ax + 1] = std::max(h[2 * ax + 1], o.box[2 * ax + 1]);
     }
   for (int n = 0; n < 6; ++n) a.hull[n] = h[n];
+  // z segment of the row kernels rotated every 2^rot block rows (lane_cell).  MI355X, two
+  // half-step launches per step with six PMLs, rot = 2 / 3 / 4: 512^3 float32 (8 segments)
+  // 1.735 / 1.794 / 1.751 ms; 256^3 float32 (4 segments) 0.237 / 0.235 / 0.233; float64 256^3
+  // 0.493 / 0.479 / 0.477 and 512^3 3.78 / 3.74 / 3.73 -- every 16 rows, except float32 rows of
+  // more than four segments.
   static const int rot = [] {
     const char* e = getenv("FDTDHIP_ROT");
-    return e ? atoi(e) : 2;
+    return e ? atoi(e) : -1;
   }();
-  a.rot_shift = rot;
+  a.rot_shift = rot >= 0 ? rot : (sizeof(T) == 8 || (p->nz + 63) / 64 <= 4 ? 4 : 2);
 }
 
 template <typename T>
