@@ -34,7 +34,8 @@ Extra objects in the JSON line:
                 timed on this machine's host cores on bounded samples (128^3 and 256^3)
   also          (one GPU, default workload, unless --no-also) the other benchmark
                 configurations measured by the same run: the headline grid with both material
-                arrays read, the headline grid over 1000 steps ("sustained"), m3, m2, m3v64, m4
+                arrays read, the headline grid over 1000 steps ("sustained"), m3, m2, m3v64, m4,
+                and a differentiable run with its reverse sweep ("adjoint")
 """
 
 import argparse
@@ -301,6 +302,27 @@ def measure_single(workload, steps, warmup, materials="auto"):
     return rec
 
 
+def measure_adjoint():
+    """configs[4] in the size of the other legs: a differentiable run (256^3 float32, six PMLs,
+    a learnable 64^3 anisotropic box, 40 steps recorded in one autograd node) and its reverse
+    sweep; milliseconds per step of each (tools/bench_adjoint.py, workload `large`)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_adjoint
+
+    best = None
+    for _ in range(2):      # the first pass warms up allocator and code objects
+        r = bench_adjoint.once("large")
+        if best is None or r["forward_ms_per_step"] + r["backward_ms_per_step"] < \
+                best["forward_ms_per_step"] + best["backward_ms_per_step"]:
+            best = r
+    return {"workload": "256x256x256 f32 6xPML(10) + learnable anisotropic 64^3, 40 steps forward "
+                        "(curl traces recorded) and backward (reverse-time adjoint)",
+            "forward_ms_per_step": round(best["forward_ms_per_step"], 4),
+            "backward_ms_per_step": round(best["backward_ms_per_step"], 4),
+            "forward_Gcells_s": round(best["forward_Gcells_s"], 2),
+            "backward_Gcells_s": round(best["backward_Gcells_s"], 2), "unit": "Gcells/s"}
+
+
 def cpu_baseline(name, budget_s=12.0):
     """The numpy oracle on bounded samples of the same scene (rank 0, N=1 only): 128^3 for
     about `budget_s` seconds, then 256^3 for 5 steps."""
@@ -510,6 +532,7 @@ def main():
         also["m2"] = measure_single("m2", 1000, 20)
         also["m3v64"] = measure_single("m3v64", 100, 10)
         also["m4"] = measure_single("m4", 100, 10)     # one GPU's share of the 8-GPU configuration
+        also["adjoint"] = measure_adjoint()
         out["also"] = also
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
