@@ -1037,7 +1037,7 @@ int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
   AdjArgs<T> a;
   if (int rc = adjoint_args<T>(p, phaseE, lamE, lamH, work, a)) return rc;
   const dim3 block(256);
-  const CellBox whole{0, p->nx, 0, p->ny, 0, p->nz};
+  const CellBoxes whole{};   // (not read by the kernels that cover the whole grid)
   if (a.direct) {
     // Only cells near a PML slab or an object have a pass 1 (the kernel leaves the others
     // out cell by cell): launch it over boxes that cover them instead of the whole grid --
@@ -1062,14 +1062,29 @@ int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
       boxes.push_back({std::max(a.hull[0] - 1, s0[0]), std::min(a.hull[1] + 1, s1[0]),
                        std::max(a.hull[2] - 1, s0[1]), std::min(a.hull[3] + 1, s1[1]),
                        std::max(a.hull[4] - 1, s0[2]), std::min(a.hull[5] + 1, s1[2])});
+    CellBoxes tab;
+    tab.count = 0;
+    tab.first[0] = 0;
     for (const CellBox& b : boxes) {
       if (b.i1 <= b.i0 || b.j1 <= b.j0 || b.k1 <= b.k0) continue;
-      const bool thin = b.k1 - b.k0 <= 16;   // several short rows per wave (box_lane_cell)
-      const int rows_per_block = thin ? 4 * (64 >> thin_box_shift(b.k1 - b.k0)) : 4;
-      const dim3 grid(thin ? 1 : (b.k1 - b.k0 + 63) / 64,
-                      (b.j1 - b.j0 + rows_per_block - 1) / rows_per_block, b.i1 - b.i0);
-      if (phaseE) hipLaunchKernelGGL((adj_E_cells<T, true, true>), grid, block, 0, p->stream, a, b);
-      else hipLaunchKernelGGL((adj_H_cells<T, true, true>), grid, block, 0, p->stream, a, b);
+      int gx, gy;
+      box_grid(b, gx, gy);
+      tab.box[tab.count] = b;
+      tab.gx[tab.count] = gx;
+      tab.gy[tab.count] = gy;
+      tab.first[tab.count + 1] = tab.first[tab.count] + (int64_t)gx * gy * (b.i1 - b.i0);
+      ++tab.count;
+    }
+    for (int n = tab.count; n < MAX_CELL_BOXES; ++n) {
+      tab.box[n] = CellBox{0, 0, 0, 0, 0, 0};
+      tab.gx[n] = tab.gy[n] = 1;
+      tab.first[n + 1] = tab.first[tab.count];
+    }
+    if (tab.first[tab.count] >= (1ll << 31)) return fail(-1, "internal: pass 1 of the adjoint over too many workgroups");
+    if (tab.count) {
+      const dim3 grid((unsigned)tab.first[tab.count]);
+      if (phaseE) hipLaunchKernelGGL((adj_E_cells<T, true, true>), grid, block, 0, p->stream, a, tab);
+      else hipLaunchKernelGGL((adj_H_cells<T, true, true>), grid, block, 0, p->stream, a, tab);
     }
   } else if (adjoint_rows(p)) {
     const dim3 grid((p->nz + 63) / 64, (p->ny + 3) / 4, p->nx);
