@@ -922,6 +922,11 @@ int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArg
   BulkArgs<T> boxes;
   fill_core<T>(p, boxes);
   for (int n = 0; n < 6; ++n) { a.hull[n] = boxes.hull[n]; a.core[n] = boxes.core[n]; }
+  for (int n = 0; n < MAX_PML; ++n) {
+    a.face_axis[n] = boxes.face_axis[n];
+    a.face_lo[n] = boxes.face_lo[n];
+    a.face_hi[n] = boxes.face_hi[n];
+  }
   a.rot_shift = boxes.rot_shift;
   // (pass 1 is then launched box by box with planes and row quads as grid dimensions)
   const int mode = adjoint_direct_mode();

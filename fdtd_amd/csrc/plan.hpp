@@ -105,6 +105,9 @@ struct AdjArgs {
   int rot_shift;       // row mapping: z-segment rotation period (as in BulkArgs)
   int direct;          // cells far from every PML and object skip pass 1, and pass 2 derives
                        // their difference adjoints from lamF itself
+  // normal axis and index range [lo, hi) of each PML face, in table order (as in BulkArgs): a
+  // wavefront reads the descriptor of a face only if one of its cells lies in that face
+  int face_axis[MAX_PML], face_lo[MAX_PML], face_hi[MAX_PML];
 };
 
 }  // namespace fdtdhip

@@ -163,6 +163,14 @@ __device__ __forceinline__ bool adj_any_pml(const AdjArgs<T>& a, int i, int j, i
                        k >= a.core[4] && k < a.core[5];
   return a.npml > 0 && !__all(in_core);
 }
+// Whether some lane's cell lies in PML face p (the ranges are kernel arguments, already in
+// scalar registers: a wave does not wait for the descriptors of faces it does not touch).
+template <typename T>
+__device__ __forceinline__ bool adj_face_touched(const AdjArgs<T>& a, int p, int i, int j, int k) {
+  const int ax = a.face_axis[p];
+  const int coord = ax == 0 ? i : (ax == 1 ? j : k);
+  return __any(coord >= a.face_lo[p] && coord < a.face_hi[p]);
+}
 template <typename T>
 __device__ __forceinline__ bool adj_any_obj(const AdjArgs<T>& a, int i, int j, int k) {
   const bool near = i >= a.hull[0] && i < a.hull[1] && j >= a.hull[2] && j < a.hull[3] &&
@@ -280,7 +288,11 @@ __device__ __forceinline__ bool adj_E_cell(const AdjArgs<T>& a, int i, int j, in
 
   // PML corrections and memory variables (they act on the final E of the half step)
   if (adj_any_pml(a, i, j, k))
-  for (int p = a.npml - 1; p >= 0; --p) {
+#pragma unroll
+  for (int q = 0; q < MAX_PML; ++q) {   // last registered first
+    const int p = MAX_PML - 1 - q;
+    if (p >= a.npml) continue;
+    if (!adj_face_touched(a, p, i, j, k)) continue;
     const PmlK<T> P = a.pml[p];
     if (P.axis == 0) adj_pml_face<T, 0>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WX_Y], G[WX_Z], store);
     else if (P.axis == 1) adj_pml_face<T, 1>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WY_Z], G[WY_X], store);
@@ -397,7 +409,11 @@ __device__ __forceinline__ void adj_H_cell(const AdjArgs<T>& a, int i, int j, in
 #pragma unroll
   for (int n = 0; n < 6; ++n) G[n] = T(0);
   if (adj_any_pml(a, i, j, k))
-  for (int p = a.npml - 1; p >= 0; --p) {
+#pragma unroll
+  for (int q = 0; q < MAX_PML; ++q) {   // last registered first
+    const int p = MAX_PML - 1 - q;
+    if (p >= a.npml) continue;
+    if (!adj_face_touched(a, p, i, j, k)) continue;
     const PmlK<T> P = a.pml[p];
     if (P.axis == 0) adj_pml_face<T, 0>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WX_Y], G[WX_Z], store);
     else if (P.axis == 1) adj_pml_face<T, 1>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WY_Z], G[WY_X], store);
