@@ -299,8 +299,9 @@ def test_staged_steps_over_rccl_equal_half_steps_bitwise():
     sums = {}
     for mode, env in (("staged", {}), ("half steps", {"FDTDHIP_FUSED": "0"})):
         port = str(slab_support.free_port())
+        base = {k: v for k, v in os.environ.items() if k != "FDTDHIP_FUSED"}   # the library's own choice
         done = subprocess.run([sys.executable, tool, "21", "small"], capture_output=True, text=True, timeout=280,
-                              env=dict(os.environ, MASTER_PORT=port, **env))
+                              env=dict(base, MASTER_PORT=port, **env))
         assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-3000:]
         line = [ln for ln in done.stdout.splitlines() if ln.startswith("state checksum")][0]
         taken = int(done.stdout.split("whole steps taken")[1].split()[0])
@@ -511,6 +512,7 @@ def test_large_slabs_take_whole_steps_by_default_and_equal_half_steps_bitwise(tm
     faces between two end slabs -- against the same run with FDTDHIP_FUSED=0 (two half-step
     launches per step), bit for bit, fields and detector readings."""
     runs = {}
+    monkeypatch.delenv("FDTDHIP_FUSED", raising=False)   # the library's own choice first
     for mode in ("default", "0"):
         if mode == "0":
             monkeypatch.setenv("FDTDHIP_FUSED", "0")
