@@ -1,0 +1,502 @@
+// Whole steps of libfdtd_hip: one launch (or a marching kernel with its shell launches) per
+// time step instead of the reference's two passes (reference fdtd/grid.py:267-273), and the
+// policy that decides which plans take them.
+#include "plan_host.hpp"
+#include "yee_generic.hpp"
+#include "yee_step.hpp"
+#include "yee_march.hpp"
+#include "yee_shell.hpp"
+
+namespace fdtdhip {
+
+// ---- fused full step (yee_step.hpp) -------------------------------------------------
+// Usable when nothing has to happen between the two half steps that the fused
+// kernel cannot do itself: no periodic boundary, no hard plane source, no x-slab
+// halo, no curl trace being recorded, at most MAX_STEP_SOURCES additive source points
+// without repeated cells, and the caller has provided the second buffers.
+constexpr int64_t FUSED_AUTO_MAX_CELLS = 1 << 17;
+
+#ifndef FDTDHIP_MARCH_TY32
+#define FDTDHIP_MARCH_TY32 4   // rows per workgroup of the marching kernel in float32 (experiments: -D)
+#endif
+#ifndef FDTDHIP_MARCH_TY64
+#define FDTDHIP_MARCH_TY64 4   // the same in float64
+#endif
+constexpr int64_t MARCH_SHELL_SHARE = 6;   // shell cells at most a sixth of the grid
+
+// Plans with PML faces take the marching step over the box no face reaches, with half steps
+// of their own for the shell around it (yee_shell.hpp).  That needs a box.
+// `hole`: the box that holds every object, clipped to the core (empty without objects): its E
+// half step belongs to the shell as well.
+namespace {
+// Whether the marching kernel itself evaluates the E half step of the cell of element `elem`.
+bool march_owns(const fdtdhip_plan* p, const int (&core)[6], const int (&hole)[6], int64_t elem) {
+  const int64_t plane = (int64_t)p->ny * p->nz, cell = elem / 3;
+  const int i = (int)(cell / plane), j = (int)((cell % plane) / p->nz), k = (int)(cell % p->nz);
+  if (i < core[0] || i >= core[1] || j < core[2] || j >= core[3] || k < core[4] || k >= core[5])
+    return false;
+  return !(i >= hole[0] && i < hole[1] && j >= hole[2] && j < hole[3] && k >= hole[4] && k < hole[5]);
+}
+
+}  // namespace
+
+bool march_core(const fdtdhip_plan* p, int (&core)[6], int (&hole)[6]) {
+  BulkArgs<float> b;
+  fill_core<float>(p, b);
+  for (int n = 0; n < 6; ++n) core[n] = b.core[n];
+  // on an x-slab the plane that reads the neighbour's H (E half step of plane 0) or E (H half
+  // step of the last plane) waits for the halo exchange: it belongs to the shell
+  if (p->H_below) core[0] = std::max(core[0], 1);
+  if (p->E_above) core[1] = std::min(core[1], p->nx - 1);
+  for (int ax = 0; ax < 3; ++ax) {
+    if (core[2 * ax + 1] - core[2 * ax] < 1) return false;
+    hole[2 * ax] = std::min(std::max(b.hull[2 * ax], core[2 * ax]), core[2 * ax + 1]);
+    hole[2 * ax + 1] = std::min(std::max(b.hull[2 * ax + 1], hole[2 * ax]), core[2 * ax + 1]);
+  }
+  if (p->objs.empty() || hole[1] == hole[0] || hole[3] == hole[2] || hole[5] == hole[4])
+    for (int n = 0; n < 6; ++n) hole[n] = 0;
+  return true;
+}
+
+// `staged`: asked by fdtdhip_step_stage, the whole step in pieces around the halo exchanges
+// of an x-slab -- the marching step or nothing.
+FusedKind fused_kind(const fdtdhip_plan* p, bool staged) {
+  // FDTDHIP_FUSED=0 never, =1 step_fused whenever possible, =2 step_march whenever possible
+  // (tests).  By default step_fused only where it was measured faster than two half-step
+  // launches (MI355X, PML on every face, tools/mid_cost.py): 2-D grids up to about 420 x 420
+  // cells (161 x 97: 9.0 against 11.4 us per step, 360^2: 12.7 / 14.1, 420^2: 15.4 / 15.7,
+  // 512^2: 17.7 / 17.1; in 3-D the lane's four E evaluations with six faces cost more than
+  // the second launch at every size tried, and on large grids the kernel is L1-bound), and
+  // step_march on 3-D grids without PMLs and objects, with z rows of 128 to 1024 cells and enough rows and
+  // planes to fill the machine with workgroups (512^3 float32: 1.25 against 1.66 ms per step,
+  // 256^3: 0.187 against 0.21, 256 x 1024 x 1024: 2.67 against 3.3; float64 512^3: 3.05 / 3.34).
+  static const int mode = [] {
+    const char* e = getenv("FDTDHIP_FUSED");
+    return e ? atoi(e) : -1;
+  }();
+  if (mode == 0 || !p->E_alt || !p->H_alt) return FUSED_NONE;
+  for (const ObjH& o : p->objs)
+    if (o.kind == FDTDHIP_OBJ_ANISOTROPIC_MODULATED) return FUSED_NONE;  // only the generic E kernel has them
+  const bool halo = p->H_below || p->E_above;
+  if (halo && !staged) return FUSED_NONE;
+  if (staged && p->trace_cursor >= 0) return FUSED_NONE;   // recorded runs on slabs: half steps
+  for (const DetH& d : p->dets)
+    if (staged && d.below) return FUSED_NONE;   // read between the post pieces and a plane exchange
+  for (const BoundaryRef& b : p->boundaries)
+    if (b.kind == 1) return FUSED_NONE;
+  for (const PmlH& h : p->pmls)
+    if (!h.psiE_alt) return FUSED_NONE;
+  int64_t points = 0;
+  for (const SourceH& s : p->sources) {
+    if (s.kind != FDTDHIP_SRC_ADD_POINTS || s.serial) return FUSED_NONE;
+    points += s.n;
+  }
+  if (points > MAX_STEP_SOURCES) return FUSED_NONE;
+  const bool cell_ok = p->nx <= 65535 && (int64_t)p->ny * p->nz < (1ll << 30) &&
+                       p->cells() * 3 < (1ll << 31);   // the kernel's element offsets are 32-bit
+  int core[6], hole[6] = {0, 0, 0, 0, 0, 0};
+  const bool whole_grid = p->pmls.empty() && p->objs.empty() && !halo;   // step_march, no shell
+  const bool march_ok = (whole_grid || march_core(p, core, hole)) &&
+                        p->nz <= 64 * MARCH_MAX_WAVES && p->nx / 16 <= 65535;
+  // the cells that take half steps of their own next to the marching kernel
+  const int64_t shell_cells = whole_grid || !march_ok ? 0 :
+      p->cells() - (int64_t)(core[1] - core[0]) * (core[3] - core[2]) * (core[5] - core[4]) +
+      (int64_t)(hole[1] - hole[0]) * (hole[3] - hole[2]) * (hole[5] - hole[4]);
+  if (mode == 1) return cell_ok && !staged ? FUSED_CELL : FUSED_NONE;
+  if (mode == 2) return march_ok ? FUSED_MARCH : FUSED_NONE;
+  const int thin = std::min(p->nx, std::min(p->ny, p->nz));
+  if (cell_ok && !staged && p->cells() <= FUSED_AUTO_MAX_CELLS && thin == 1) return FUSED_CELL;
+  // (with material arrays to read, the shell's half steps cost more than the marching kernel
+  // saves: 512^3 float32, six faces and two 64^3 boxes, 2.44 against 2.26 ms per step)
+  if (!(p->mat_const[0] && p->mat_const[1]) && !(p->pmls.empty() && p->objs.empty())) return FUSED_NONE;
+  // (PML faces and objects: the shell and the box of the objects take half steps of their
+  // own at a third of the marching kernel's rate per cell -- worth it while they are few)
+  // (256^3 with six ten-cell faces, 22 % of the cells: float64 0.489 against 0.508 ms per step
+  // in a bare loop and no difference in the benchmark, float32 0.256 against 0.235)
+  if (march_ok && p->nz >= 128 && p->ny >= 64 && p->nx >= 64 && p->cells() >= (1ll << 22) &&
+      shell_cells * MARCH_SHELL_SHARE <= p->cells())
+    return FUSED_MARCH;
+  return FUSED_NONE;
+}
+
+namespace {
+
+// Build the detector map of the fused step once per plan layout.
+int build_detmap(fdtdhip_plan* p) {
+  p->detmap_state = -1;
+  p->detmap = nullptr;   // an earlier map stays in `owned` until the plan is reset
+  int cells_dets = 0;
+  for (const DetH& d : p->dets)
+    if (d.kind == FDTDHIP_DET_CELLS && d.n > 0) ++cells_dets;
+  if (cells_dets == 0 || cells_dets > MAX_STEP_DETECTORS) return 0;
+  std::vector<int32_t> map((size_t)p->cells(), -1);
+  int slot = 0;
+  for (const DetH& d : p->dets) {
+    if (d.kind != FDTDHIP_DET_CELLS || d.n == 0) continue;
+    if (d.n >= (1 << 24)) return 0;
+    for (int64_t n = 0; n < d.n; ++n) {
+      int32_t& m = map[(size_t)d.cell_host[n]];
+      if (m >= 0) return 0;  // a cell read twice: leave it to the detector kernels
+      m = (slot << 24) | (int32_t)n;
+    }
+    ++slot;
+  }
+  HIPCHK(hipMalloc((void**)&p->detmap, sizeof(int32_t) * map.size()));
+  p->owned.push_back(p->detmap);
+  HIPCHK(hipMemcpy(p->detmap, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice));
+  p->detmap_state = 1;
+  return 0;
+}
+
+}  // namespace
+
+// Workgroups of `kernel` (blocks of `threads`) that the GPU of the plan holds at once.
+int march_slots(fdtdhip_plan* p, const void* kernel, int threads) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> per_cu;
+  static std::map<int, int> cus;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_pair(kernel, threads);
+  if (!per_cu.count(key)) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess || n < 1) n = 2;
+    per_cu[key] = n;
+  }
+  if (!cus.count(p->device)) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || n < 1) n = 256;
+    cus[p->device] = n;
+  }
+  return per_cu[key] * cus[p->device];
+}
+
+// Planes per chunk of the marching kernels.  A workgroup takes one tile of rows through one
+// chunk of planes; all of them should keep the machine busy in whole rounds: 960 workgroups on
+// 768 places (256^3 float64 with six faces) left three quarters of the CUs idle for a fifth of
+// the launch (340 -> 323 us).  Among the chunk lengths of 16 to 128 planes the one with the
+// fullest rounds wins, counting the plane every chunk evaluates past its end, and a single
+// round counting 3 % less than several (512^3 float32: 4 chunks of 128 planes in one round
+// 1.215 ms, 8 chunks of 64 in two rounds 1.183).
+int march_chunk_planes(int planes, int tiles, int slots) {
+  static const int forced_lx = [] {
+    const char* e = getenv("FDTDHIP_MARCH_LX");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced_lx > 0) return forced_lx;
+  int best_lx = std::min(planes, 128);
+  double best = -1;
+  for (int chunks = 1; chunks <= std::max(1, planes / 16); ++chunks) {
+    const int lx = (planes + chunks - 1) / chunks;
+    if (lx > 128) continue;
+    const int64_t wgs = (int64_t)tiles * ((planes + lx - 1) / lx);
+    const int64_t rounds = (wgs + slots - 1) / slots;
+    const double score = (double)wgs / (double)(rounds * slots) * lx / (lx + 1.0) * (rounds >= 2 ? 1.0 : 0.97);
+    if (score > best + 1e-9) { best = score; best_lx = lx; }
+  }
+  return std::max(best_lx, 1);
+}
+
+namespace {
+
+// The marching step (yee_march.hpp) over the whole grid: plans without PMLs, objects and
+// open slab faces.  (The kernel carries no PML code: with the face code evaluated row after
+// row every workgroup waited, plane by plane, for its two waves on the z faces to walk their
+// chain of memory-variable round trips -- 512^3 float32, six faces: 4.6 ms per step with 2
+// rows, 6.2 ms with 3, against 1.81 ms for two half-step launches.  Plans with faces split
+// off a shell instead, see launch_march_shell.)
+template <typename T, int TY, int MW>
+int launch_march_tiles(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
+  MarchArgs<T> m;
+  m.s = a;
+  m.chunk0 = 0;
+  const int tiles = (p->ny + TY - 1) / TY;
+  const int waves = (p->nz + 63) / 64;
+  const bool constants = p->mat_const[0] && p->mat_const[1];
+  // (a kernel limited to 8 waves per workgroup may use 256 registers, one for z rows of up to
+  // 1024 cells 128)
+  void (*kernel)(MarchArgs<T>) = obj ? step_march<T, TY, false, true, false, MW>
+                                 : constants ? step_march<T, TY, false, false, true, MW>
+                                             : step_march<T, TY, false, false, false, MW>;
+  const int lx = m.lx = march_chunk_planes(p->nx, tiles, march_slots(p, (const void*)kernel, 64 * waves));
+  // tiles dealt to the XCDs in bands (see step_march); FDTDHIP_MARCH_BAND=0: plain order
+  static const bool banded = [] {
+    const char* e = getenv("FDTDHIP_MARCH_BAND");
+    return !e || atoi(e) != 0;
+  }();
+  m.band = banded && tiles >= 16 ? (tiles + 7) / 8 : 0;
+  const dim3 grid(m.band ? 8 * m.band : tiles, (p->nx + lx - 1) / lx, 1), block(64 * waves);
+  hipLaunchKernelGGL(kernel, grid, block, 0, p->stream, m);
+  return 0;
+}
+
+// Rows per workgroup and workgroup size of the marching kernels.  float32: 4 rows.  float64:
+// 4 rows in workgroups of up to 8 waves (z rows of up to 512 cells: 160-168 registers, 3 waves
+// per SIMD; 512^3 vacuum 2.43 ms per step against 2.53 with 2 rows -- 1, 3, 6 and 8 rows:
+// 2.98, 2.92, 2.76, 2.74), 2 rows in the 16-wave workgroups of longer z rows, which may use
+// 128 registers and would spill with 4.  (float32 with 2, 3, 5, 6, 8 rows: 1.22, 1.45, 1.38,
+// 1.36, 1.18 against 1.19 ms with 4.)
+template <typename T>
+int launch_march(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
+  if ((p->nz + 63) / 64 <= 8)
+    return launch_march_tiles<T, sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : FDTDHIP_MARCH_TY64, 8>(p, a, obj);
+  return launch_march_tiles<T, sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : 2, MARCH_MAX_WAVES>(p, a, obj);
+}
+
+// The marching step of a plan with PML faces, objects or open slab faces, in pieces: E half
+// step of the shell, the marching kernel over the core, H half step of the shell
+// (yee_shell.hpp).  On an x-slab two planes wait for a neighbour's plane -- plane 0 in the E
+// half step, the last plane in the H half step -- and the marching kernel comes in two
+// launches over halves of its chunks of planes, so that a caller can run
+//   E of the shell without plane 0, first half of the core      while H_below arrives,
+//   E of plane 0                                                 (then sends its new E),
+//   second half of the core, H of the shell without the last plane   while E_above arrives,
+//   H of the last plane.
+// The marching kernel reads the new E of plane 0 nowhere (its lowest plane is plane 1 at
+// least, whose H half step reads plane 2), so the order is that of two half steps for every
+// operand.  Without open faces all pieces are enqueued at once, the core in one launch.
+
+template <typename T, int TY, int MW>
+int launch_march_shell_tiles(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, int stages) {
+  int c[6], hole[6];
+  if (!march_core(p, c, hole)) return fail(-1, "internal: no core box for the marching step");
+  const int nx = p->nx, ny = p->ny, nz = p->nz;
+  const int e_lo = p->H_below ? 1 : 0;        // E half step: plane 0 waits for H_below
+  const int h_hi = p->E_above ? nx - 1 : nx;  // H half step: the last plane waits for E_above
+  // the shell as disjoint boxes: x slabs over everything, y slabs between them, z slabs
+  // inside; and the box of the objects, for the E half step only
+  auto table = [&](std::initializer_list<ShellBox> boxes) {
+    Shell sh;
+    sh.count = 0;
+    sh.first[0] = 0;
+    for (const ShellBox& b : boxes) {
+      const int64_t n = (int64_t)std::max(b.i1 - b.i0, 0) * std::max(b.j1 - b.j0, 0) * std::max(b.k1 - b.k0, 0);
+      if (n == 0) continue;
+      sh.box[sh.count] = b;
+      sh.first[sh.count + 1] = sh.first[sh.count] + blocks_for(n);
+      ++sh.count;
+    }
+    for (int n = sh.count; n < MAX_SHELL_BOXES; ++n) {
+      sh.box[n] = ShellBox{0, 0, 0, 0, 0, 0};
+      sh.first[n + 1] = sh.first[sh.count];
+    }
+    return sh;
+  };
+  const ShellBox ylow{c[0], c[1], 0, c[2], 0, nz}, yhigh{c[0], c[1], c[3], ny, 0, nz},
+      zlow{c[0], c[1], c[2], c[3], 0, c[4]}, zhigh{c[0], c[1], c[2], c[3], c[5], nz};
+  const bool pml = !p->pmls.empty();
+  size_t slot;
+  auto shell_e = [&](const Shell& sh) -> int {
+    if (!sh.count) return 0;
+    if (int rc = span_begin(p, slot)) return rc;
+    const dim3 grid((unsigned)sh.first[sh.count]), block(256);
+    if (pml && obj) hipLaunchKernelGGL((shell_E<T, true, true>), grid, block, 0, p->stream, a.e, a.E1, sh);
+    else if (pml) hipLaunchKernelGGL((shell_E<T, true, false>), grid, block, 0, p->stream, a.e, a.E1, sh);
+    else if (obj) hipLaunchKernelGGL((shell_E<T, false, true>), grid, block, 0, p->stream, a.e, a.E1, sh);
+    else hipLaunchKernelGGL((shell_E<T, false, false>), grid, block, 0, p->stream, a.e, a.E1, sh);
+    HIPCHK(hipGetLastError());
+    return span_end(p, slot, TIME_SHELL);
+  };
+  auto shell_h = [&](const Shell& sh) -> int {
+    if (!sh.count) return 0;
+    if (int rc = span_begin(p, slot)) return rc;
+    BulkArgs<T> h = a.h;
+    h.G = a.E1;     // the H half step is driven by the new E
+    const dim3 grid((unsigned)sh.first[sh.count]), block(256);
+    if (pml) hipLaunchKernelGGL((shell_H<T, true>), grid, block, 0, p->stream, h, a.H1, sh);
+    else hipLaunchKernelGGL((shell_H<T, false>), grid, block, 0, p->stream, h, a.H1, sh);
+    HIPCHK(hipGetLastError());
+    return span_end(p, slot, TIME_SHELL);
+  };
+  // source points: the marching kernel adds those on cells whose E half step it evaluates,
+  // the others are added to the shell's new E once that is written (plane 0 of an open slab
+  // apart from the rest)
+  MarchArgs<T> m;
+  m.s = a;
+  ShellSources<T> ss_free, ss_ghost;
+  ss_free.n = ss_ghost.n = m.s.nsrc = 0;
+  const int64_t plane3 = (int64_t)ny * nz * 3;
+  for (int n = 0; n < a.nsrc; ++n) {
+    if (march_owns(p, c, hole, a.src_elem[n])) {
+      m.s.src_elem[m.s.nsrc] = a.src_elem[n];
+      m.s.src_value[m.s.nsrc++] = a.src_value[n];
+    } else {
+      ShellSources<T>& ss = e_lo && a.src_elem[n] < plane3 ? ss_ghost : ss_free;
+      ss.elem[ss.n] = a.src_elem[n];
+      ss.value[ss.n++] = a.src_value[n];
+    }
+  }
+  if (stages & ST_E_FREE) {
+    if (int rc = shell_e(table({{e_lo, c[0], 0, ny, 0, nz}, {c[1], nx, 0, ny, 0, nz}, ylow, yhigh, zlow, zhigh,
+                                {hole[0], hole[1], hole[2], hole[3], hole[4], hole[5]}})))
+      return rc;
+    if (ss_free.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, a.E1, ss_free);
+  }
+  if (stages & ST_E_GHOST) {
+    if (int rc = shell_e(table({{0, e_lo, 0, ny, 0, nz}}))) return rc;
+    if (ss_ghost.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, a.E1, ss_ghost);
+  }
+  if (stages & (ST_MARCH_A | ST_MARCH_B)) {
+    for (int n = 0; n < 6; ++n) { m.box[n] = c[n]; m.hole[n] = hole[n]; }
+    const bool holed = hole[1] > hole[0];
+    const int tiles = (c[3] - c[2] + TY - 1) / TY, planes = c[1] - c[0];
+    const int waves = (nz + 63) / 64;
+    const bool constants = p->mat_const[0] && p->mat_const[1];
+    void (*kernel)(MarchArgs<T>) = holed ? (constants ? step_march_box<T, TY, true, true, MW>
+                                                      : step_march_box<T, TY, true, false, MW>)
+                                         : (constants ? step_march_box<T, TY, false, true, MW>
+                                                      : step_march_box<T, TY, false, false, MW>);
+    const bool both = (stages & ST_MARCH_A) && (stages & ST_MARCH_B);
+    // (in two launches: each half of the planes should fill its rounds)
+    const int lx = m.lx = march_chunk_planes(both ? planes : (planes + 1) / 2, tiles,
+                                             march_slots(p, (const void*)kernel, 64 * waves));
+    const int nchunks = (planes + lx - 1) / lx, half = nchunks / 2;
+    m.band = tiles >= 16 ? (tiles + 7) / 8 : 0;
+    m.chunk0 = both || (stages & ST_MARCH_A) ? 0 : half;
+    const int count = both ? nchunks : ((stages & ST_MARCH_A) ? half : nchunks - half);
+    if (count > 0) {
+      const dim3 grid(m.band ? 8 * m.band : tiles, count, 1), block(64 * waves);
+      if (int rc = span_begin(p, slot)) return rc;
+      hipLaunchKernelGGL(kernel, grid, block, 0, p->stream, m);
+      HIPCHK(hipGetLastError());
+      if (int rc = span_end(p, slot, TIME_WHOLE)) return rc;
+    }
+  }
+  if (stages & ST_H_FREE)
+    if (int rc = shell_h(table({{0, c[0], 0, ny, 0, nz}, {c[1], h_hi, 0, ny, 0, nz}, ylow, yhigh, zlow, zhigh})))
+      return rc;
+  if (stages & ST_H_GHOST)
+    if (int rc = shell_h(table({{h_hi, nx, 0, ny, 0, nz}}))) return rc;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int launch_march_shell(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, int stages) {
+  if ((p->nz + 63) / 64 <= 8)
+    return launch_march_shell_tiles<T, sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : FDTDHIP_MARCH_TY64, 8>(p, a, obj, stages);
+  return launch_march_shell_tiles<T, sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : 2, MARCH_MAX_WAVES>(p, a, obj, stages);
+}
+
+// Kernel arguments of a whole step at time index q (both half steps, the second buffers,
+// the additive source points with their values).
+template <typename T>
+int step_args(fdtdhip_plan* p, int64_t q, bool march, StepArgs<T>& a) {
+  if (int rc = sync_obj_table<T>(p)) return rc;
+  for (int phase = 0; phase < 2; ++phase) {
+    const bool phaseE = phase == 0;
+    BulkArgs<T>& b = phaseE ? a.e : a.h;
+    b.F = (T*)(phaseE ? p->E : p->H);
+    b.G = (const T*)(phaseE ? p->H : p->E);
+    b.mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
+    b.ghost = (const T*)(phaseE ? p->H_below : p->E_above);   // (open slab faces: marching step only)
+    b.nx = p->nx; b.ny = p->ny; b.nz = p->nz;
+    b.x0 = 0; b.x1 = p->nx;
+    b.sc = (T)p->sc;
+    b.npml = (int)p->pmls.size();
+    b.nobj = phaseE ? (int)p->objs.size() : 0;
+    b.obj = (const ObjK<T>*)p->obj_table;
+    b.trace_step = phaseE ? p->trace_cursor : -1;   // the owner lane records the curl
+    fill_core<T>(p, b);
+    fill_material<T>(p, phaseE, b);
+  }
+  if (int rc = sync_pml_tables<T>(p)) return rc;
+  // p->step_flipped: the state currently lives in the second buffers
+  // (the marching step advances the memory variables in place: its shell cells are evaluated once)
+  a.e.pml = pml_table<T>(p, march ? TAB_E : (p->step_flipped ? TAB_E_BA : TAB_E_AB));
+  a.h.pml = pml_table<T>(p, TAB_H);
+  a.E1 = (T*)p->E_alt;
+  a.H1 = (T*)p->H_alt;
+  a.nsrc = 0;
+  a.detmap = nullptr;
+  for (int slot = 0; slot < MAX_STEP_DETECTORS; ++slot) a.detE[slot] = a.detH[slot] = nullptr;
+  for (const SourceH& s : p->sources) {
+    const double w = waveform(s, q);
+    for (int64_t i = 0; i < s.n; ++i) {
+      if (a.nsrc >= MAX_STEP_SOURCES) return fail(-1, "internal: too many source points for a whole step");
+      a.src_elem[a.nsrc] = s.elem_host[i];
+      a.src_value[a.nsrc] = (T)(s.profile_host[i] * w);
+      ++a.nsrc;
+    }
+  }
+  return 0;
+}
+
+// What follows the kernels of a whole step: the second buffers now hold the current state.
+template <typename T>
+int step_finish(fdtdhip_plan* p, int64_t q, bool cells_read) {
+  std::swap(p->E, p->E_alt);
+  std::swap(p->H, p->H_alt);
+  p->step_flipped = !p->step_flipped;  // psi_E follows through the two fused PML tables
+  if (cells_read) {
+    // cell-list detectors were read by the kernel; empty ones and loop currents remain
+    for (DetH& d : p->dets) {
+      if (d.kind == FDTDHIP_DET_CELLS) { ++d.usedE; ++d.usedH; }
+    }
+    advance_trace_cursor(p);
+    return half_post(p, false, q, POST_FINISH | POST_SKIP_CELL_DETECTORS);
+  }
+  if (int rc = half_post(p, true, q, POST_FINISH)) return rc;
+  return half_post(p, false, q, POST_FINISH);
+}
+
+template <typename T>
+int fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {
+  const bool march = kind == FUSED_MARCH;   // reads no detectors itself
+  if (!march && p->detmap_state == 0)
+    if (int rc = build_detmap(p)) return rc;
+  StepArgs<T> a;
+  if (int rc = step_args<T>(p, q, march, a)) return rc;
+  if (!march && p->detmap_state == 1) {
+    int slot = 0;
+    for (DetH& d : p->dets) {
+      if (d.kind != FDTDHIP_DET_CELLS || d.n == 0) continue;
+      if (!d.outE || !d.outH || d.usedE >= d.capacity || d.usedH >= d.capacity)
+        return fail(-3, "detector output capacity exhausted");
+      if (slot >= MAX_STEP_DETECTORS) return fail(-1, "detector map out of date");
+      a.detE[slot] = (T*)d.outE + d.usedE * d.n * 3;
+      a.detH[slot] = (T*)d.outH + d.usedH * d.n * 3;
+      ++slot;
+    }
+    a.detmap = p->detmap;
+  }
+  const int64_t plane = (int64_t)p->ny * p->nz;
+  const dim3 grid((unsigned)((plane + 255) / 256), p->nx, 1), block(256);
+  const bool pml = a.e.npml > 0, obj = a.e.nobj > 0;
+  if (march && (pml || obj)) {
+    if (int rc = launch_march_shell<T>(p, a, obj, ST_ALL)) return rc;
+  } else {
+    size_t slot;
+    if (int rc = span_begin(p, slot)) return rc;
+    if (march) {
+      if (int rc = launch_march<T>(p, a, obj)) return rc;
+    } else if (pml && obj) hipLaunchKernelGGL((step_fused<T, true, true>), grid, block, 0, p->stream, a);
+    else if (pml) hipLaunchKernelGGL((step_fused<T, true, false>), grid, block, 0, p->stream, a);
+    else if (obj) hipLaunchKernelGGL((step_fused<T, false, true>), grid, block, 0, p->stream, a);
+    else hipLaunchKernelGGL((step_fused<T, false, false>), grid, block, 0, p->stream, a);
+    HIPCHK(hipGetLastError());
+    if (int rc = span_end(p, slot, TIME_WHOLE)) return rc;
+  }
+  return step_finish<T>(p, q, a.detmap != nullptr);
+}
+
+// One piece of a whole step on an x-slab (fdtdhip_step_stage).
+template <typename T>
+int staged_step(fdtdhip_plan* p, int64_t q, int stage) {
+  StepArgs<T> a;
+  if (int rc = step_args<T>(p, q, true, a)) return rc;
+  static const int pieces[4] = {ST_E_FREE | ST_MARCH_A, ST_E_GHOST, ST_MARCH_B | ST_H_FREE, ST_H_GHOST};
+  if (int rc = launch_march_shell<T>(p, a, a.e.nobj > 0, pieces[stage])) return rc;
+  return stage == 3 ? step_finish<T>(p, q, false) : 0;
+}
+
+}  // namespace
+
+int whole_fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {
+  return DISPATCH(p, fused_step<float>(p, q, kind), fused_step<double>(p, q, kind));
+}
+
+int whole_staged_step(fdtdhip_plan* p, int64_t q, int stage) {
+  return DISPATCH(p, staged_step<float>(p, q, stage), staged_step<double>(p, q, stage));
+}
+
+}  // namespace fdtdhip

@@ -1,7 +1,9 @@
 """Registers, scratch, LDS and occupancy of every kernel of libfdtd_hip, as the compiler
 reports them (hipcc -Rpass-analysis=kernel-resource-usage; no GPU needed):
 
-    python tools/kernel_resources.py [substring of the kernel name ...]
+    python tools/kernel_resources.py [--unit launch_whole] [substring of the kernel name ...]
+
+Units: launch_half, launch_whole (default), launch_adjoint.
 """
 import os
 import re
@@ -9,7 +11,12 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "fdtd_amd", "csrc", "fdtd_hip.hip")
+unit = "launch_whole"
+if "--unit" in sys.argv:
+    at = sys.argv.index("--unit")
+    unit = sys.argv[at + 1]
+    del sys.argv[at:at + 2]
+src = os.path.join(ROOT, "fdtd_amd", "csrc", unit + ".hip")
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"]
 text = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.dirname(src)).stderr
