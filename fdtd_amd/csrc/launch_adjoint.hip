@@ -353,19 +353,26 @@ namespace {
 constexpr int NOALLOC_MAX_DEVICES = 64;
 std::mutex g_scratch_mutex;
 unsigned char* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+// Recorded on the stream of the last sweep that used the device's scratch array, behind its
+// last kernel: the next sweep, on whatever plan and stream, starts behind it.
+hipEvent_t g_scratch_idle[NOALLOC_MAX_DEVICES] = {};
 
-// Device address of `scratch` on `device`, which must be the current device.  Looked up once
-// per device.
-int noalloc_scratch(int device, unsigned char** out) {
+// Device address of `scratch` on `device`, which must be the current device, and the event
+// that orders its users.  Looked up / created once per device.
+int noalloc_scratch(int device, unsigned char** out, hipEvent_t* idle) {
   if (device < 0 || device >= NOALLOC_MAX_DEVICES) return fail(-1, "device ordinal out of range");
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   if (!g_scratch_ptr[device]) {
     void* ptr = nullptr;
     HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
     if (!ptr) return fail(-2, "hipGetSymbolAddress returned no address for the scratch array");
+    hipEvent_t ev = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    g_scratch_idle[device] = ev;
     g_scratch_ptr[device] = (unsigned char*)ptr;
   }
   *out = g_scratch_ptr[device];
+  *idle = g_scratch_idle[device];
   return 0;
 }
 
@@ -384,7 +391,10 @@ int adjoint_run_noalloc(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH)
     return fail(-7, "fdtdhip_adjoint_run_noalloc: more than " + std::to_string(NOALLOC_MAX_OBJECTS) +
                         " objects; use fdtdhip_adjoint_run");
   unsigned char* base = nullptr;
-  if (int rc = noalloc_scratch(p->device, &base)) return rc;
+  hipEvent_t idle = nullptr;
+  if (int rc = noalloc_scratch(p->device, &base, &idle)) return rc;
+  // a sweep enqueued earlier on another stream may still read the array
+  HIPCHK(hipStreamWaitEvent(p->stream, idle, 0));
   // the scratch array keeps whatever the last call left: both work arrays start at zero,
   // as the arrays callers hand to fdtdhip_adjoint_run do
   unsigned char* work = base + NOALLOC_WORK_OFF;
@@ -412,6 +422,8 @@ int adjoint_run_noalloc(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH)
   p->pml_dirty = pml_dirty;
   p->adj_work = adj_work;
   p->adj_work_bytes = adj_work_bytes;
+  // (recorded after a failed sweep too: what it did enqueue still uses the array)
+  HIPCHK(hipEventRecord(idle, p->stream));
   return rc;
 }
 

@@ -321,9 +321,10 @@ int fdtdhip_plan_set_object_modifier(fdtdhip_plan* plan, int id, const void* wei
 int fdtdhip_plan_set_pml_adjoint(fdtdhip_plan* plan, int id, void* lam_psiE, void* lam_psiH);
 int fdtdhip_adjoint_run(fdtdhip_plan* plan, int64_t nsteps, void* lamE, void* lamH, void* work);
 
-/* fdtdhip_adjoint_run for callers that cannot allocate device memory: code under HIP graph
- * capture, tight serving / training loops, harnesses that forbid hipMalloc.  No counterpart
- * in the reference.  Same inputs, outputs and results as fdtdhip_adjoint_run, without its
+/* fdtdhip_adjoint_run for callers that cannot allocate device memory: tight serving /
+ * training loops, harnesses that forbid hipMalloc, code that must not disturb a caching
+ * allocator.  (Not for use while a HIP graph is being captured: the call waits for the
+ * stream, see below.)  No counterpart in the reference.  Same inputs, outputs and results as fdtdhip_adjoint_run, without its
  * `work` argument: the work array, the second one the paired launches of small grids use,
  * and the PML / object descriptor tables live in one static device array of
  * FDTDHIP_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process
@@ -333,9 +334,11 @@ int fdtdhip_adjoint_run(fdtdhip_plan* plan, int64_t nsteps, void* lamE, void* la
  *   16384 + 2 * cells * 6 * sizeof(element) <= FDTDHIP_NOALLOC_SCRATCH_BYTES, the first of
  *   the two arrays rounded up to 256 bytes (349 354 cells in float64, 698 709 in float32),
  *   and at most 128 objects.
- * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two host
- * threads, two streams) race; calls one after the other, on any plans, are fine -- the work
- * arrays are cleared at the start of each call. */
+ * All calls on one GPU share that GPU's array.  Calls made one after the other from the host,
+ * on any plans and streams, are ordered by the library: the sweep of each call waits, on its
+ * own stream, for the event the call before it recorded behind its last kernel, and the work
+ * arrays are cleared at the start of each call.  Calls made at the same time from two host
+ * threads on one GPU race. */
 #define FDTDHIP_NOALLOC_SCRATCH_BYTES (32u << 20)
 int fdtdhip_adjoint_run_noalloc(fdtdhip_plan* plan, int64_t nsteps, void* lamE, void* lamH);
 

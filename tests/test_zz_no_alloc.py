@@ -108,6 +108,30 @@ class _Scene:
             out[f"lam_psiE{n}"], out[f"lam_psiH{n}"] = le, lh
         return {k: v.cpu().numpy() for k, v in out.items()}
 
+    def prepare_noalloc(self):
+        """Fresh adjoint arrays for a sweep (made on torch's stream: synchronise before
+        enqueue_noalloc)."""
+        import torch
+
+        lib, h = self.lib, self.h
+        lamE, lamH = (t.clone() for t in self.lam0)
+        lampsi = [(a.clone(), b.clone()) for a, b in self.lampsi0]
+        grad = torch.zeros_like(self.tensor)
+        _lib.check(lib.fdtdhip_plan_set_object_trace(h, self.aid, _p(self.trace), self.steps))
+        _lib.check(lib.fdtdhip_plan_set_object_grad(h, self.aid, _p(grad)))
+        for (pid, _, _), (le, lh) in zip(self.psi, lampsi):
+            _lib.check(lib.fdtdhip_plan_set_pml_adjoint(h, pid, _p(le), _p(lh)))
+        out = {"lamE": lamE, "lamH": lamH, "grad": grad}
+        for n, (le, lh) in enumerate(lampsi):
+            out[f"lam_psiE{n}"], out[f"lam_psiH{n}"] = le, lh
+        return out
+
+    def enqueue_noalloc(self, stream, arrays):
+        """The no-allocation sweep enqueued on `stream`, without waiting for it."""
+        lib, h = self.lib, self.h
+        _lib.check(lib.fdtdhip_plan_set_stream(h, ctypes.c_void_p(stream.cuda_stream)))
+        _lib.check(lib.fdtdhip_adjoint_run_noalloc(h, self.steps, _p(arrays["lamE"]), _p(arrays["lamH"])))
+
     def close(self):
         assert self.lib.fdtdhip_plan_destroy(self.h) == 0
 
@@ -140,6 +164,33 @@ def test_noalloc_reverse_sweep_equals_the_allocating_one_twice_in_a_row():
     finally:
         big.close()
         small.close()
+
+
+def test_noalloc_calls_on_two_plans_and_two_streams_back_to_back():
+    """Every call on a GPU shares that GPU's scratch array.  A second call -- another plan,
+    another non-blocking stream -- made while the first sweep is still running must wait for
+    it instead of clearing the array under it."""
+    import torch
+
+    lib = _lib.load()
+    long = _Scene(lib, (48, 40, 36), _lib.F64, steps=60, seed=21, scan=True, periodic_z=True)
+    short = _Scene(lib, (30, 22, 1), _lib.F32, steps=12, seed=22, scan=False)
+    try:
+        want_long, want_short = long.sweep(noalloc=False), short.sweep(noalloc=False)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        got_long, got_short = long.prepare_noalloc(), short.prepare_noalloc()
+        torch.cuda.synchronize()
+        long.enqueue_noalloc(s1, got_long)      # some milliseconds of kernels on s1 ...
+        short.enqueue_noalloc(s2, got_short)    # ... and the next user of the array right behind
+        torch.cuda.synchronize()
+        for scene in (long, short):
+            _lib.check(lib.fdtdhip_plan_set_stream(scene.h, None))
+        for got, want in ((got_long, want_long), (got_short, want_short)):
+            for name in want:
+                assert np.array_equal(got[name].cpu().numpy(), want[name]), f"{name} differs"
+    finally:
+        long.close()
+        short.close()
 
 
 def test_noalloc_refuses_what_does_not_fit():
