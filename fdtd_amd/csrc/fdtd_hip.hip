@@ -456,8 +456,10 @@ int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
       for (int k = 0; k < 2; ++k) {
         const int rc = whole_fused_step(p, q0 + s + k, kind);
         if (rc) {
-          // the state of the fields now sits in the second buffers (or between the two sets)
-          if (p->step_flipped) p->poisoned = true;
+          // the state of the fields now sits in the second buffers (or between the two sets);
+          // the marching step advances PML memory variables in place as it goes, so with
+          // faces a failed step cannot be repeated whichever buffers hold the fields
+          if (p->step_flipped || (kind == FUSED_MARCH && !p->pmls.empty())) p->poisoned = true;
           return rc;
         }
       }
@@ -546,6 +548,22 @@ int fdtdhip_plan_set_pml_adjoint(fdtdhip_plan* p, int id, void* lam_psiE, void* 
   if (id < 0 || id >= (int)p->pmls.size()) return fail(-1, "unknown PML id");
   p->pmls[id].lamE = lam_psiE;
   p->pmls[id].lamH = lam_psiH;
+  p->pml_dirty = true;
+  return 0;
+}
+
+int fdtdhip_plan_set_adjoint_buffers(fdtdhip_plan* p, void* lamE_alt, void* lamH_alt) {
+  if (!p) return fail(-1, "null plan");
+  p->adjE_alt = lamE_alt;
+  p->adjH_alt = lamH_alt;
+  return 0;
+}
+
+int fdtdhip_plan_set_pml_adjoint_buffers(fdtdhip_plan* p, int id, void* lam_psiE_alt, void* lam_psiH_alt) {
+  if (!p) return fail(-1, "null plan");
+  if (id < 0 || id >= (int)p->pmls.size()) return fail(-1, "unknown PML id");
+  p->pmls[id].lamE_alt = lam_psiE_alt;
+  p->pmls[id].lamH_alt = lam_psiH_alt;
   p->pml_dirty = true;
   return 0;
 }

@@ -5,6 +5,7 @@
 #include "yee_generic.hpp"
 #include "yee_tiled.hpp"
 #include "yee_adjoint.hpp"
+#include "yee_adjoint_march.hpp"
 
 namespace fdtdhip {
 
@@ -31,8 +32,9 @@ int adjoint_direct_mode() {
   return mode;
 }
 
+// `flip`: 0 the memory-variable adjoints in place, 1 from the first to the second arrays, 2 back
 template <typename T>
-int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArgs<T>& a) {
+int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArgs<T>& a, int flip = 0) {
   a.lamF = phaseE ? lamE : lamH;
   a.lamG = phaseE ? lamH : lamE;
   a.mat = (const T*)(phaseE ? p->inv_eps : p->inv_mu);
@@ -46,7 +48,8 @@ int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArg
   for (const PmlH& h : p->pmls)
     if (!(phaseE ? h.lamE : h.lamH)) return fail(-1, "PML adjoint arrays not set");
   if (int rc = sync_pml_tables<T>(p)) return rc;
-  a.pml = pml_table<T>(p, phaseE ? TAB_ADJ_E : TAB_ADJ_H);
+  a.pml = pml_table<T>(p, phaseE ? (flip == 0 ? TAB_ADJ_E : (flip == 1 ? TAB_ADJ_E_AB : TAB_ADJ_E_BA))
+                                 : (flip == 0 ? TAB_ADJ_H : (flip == 1 ? TAB_ADJ_H_AB : TAB_ADJ_H_BA)));
   a.open_lo = p->H_below ? 1 : 0;
   a.open_hi = p->E_above ? 1 : 0;
   a.wghost = nullptr;
@@ -68,6 +71,65 @@ int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArg
                      (p->ny + 3) / 4 <= 65535 &&
                      (mode > 1 || adjoint_rows(p) || p->cells() > (int64_t)(1 << 19)) ? 1 : 0;
   return 0;
+}
+
+// Launch table of a list of boxes (empty ones left out).
+int cell_box_table(const std::vector<CellBox>& boxes, CellBoxes& tab) {
+  tab.count = 0;
+  tab.first[0] = 0;
+  for (const CellBox& b : boxes) {
+    if (b.i1 <= b.i0 || b.j1 <= b.j0 || b.k1 <= b.k0) continue;
+    if (tab.count >= MAX_CELL_BOXES) return fail(-1, "internal: too many boxes for one launch");
+    int gx, gy;
+    box_grid(b, gx, gy);
+    tab.box[tab.count] = b;
+    tab.gx[tab.count] = gx;
+    tab.gy[tab.count] = gy;
+    tab.first[tab.count + 1] = tab.first[tab.count] + (int64_t)gx * gy * (b.i1 - b.i0);
+    ++tab.count;
+  }
+  for (int m = tab.count; m < MAX_CELL_BOXES; ++m) {
+    tab.box[m] = CellBox{0, 0, 0, 0, 0, 0};
+    tab.gx[m] = tab.gy[m] = 1;
+    tab.first[m + 1] = tab.first[tab.count];
+  }
+  if (tab.first[tab.count] >= (1ll << 31))
+    return fail(-1, "internal: pass 1 of the adjoint over too many workgroups");
+  return 0;
+}
+
+// The cells that keep the two-pass form when the plain ones do not (AdjArgs::direct): six
+// slabs around the part of the PML-free core whose 3x3x3 blocks stay inside it ([s0, s1) per
+// axis), and the hull of the objects grown by one cell where it lies in that part (`hole`,
+// all zero without objects).  The boxes are disjoint: pass 1 has side effects
+// (memory-variable adjoints, object gradients).
+template <typename T>
+int adjoint_shell_boxes(const fdtdhip_plan* p, const AdjArgs<T>& a, CellBoxes& tab, int (&s0)[3],
+                        int (&s1)[3], int (&hole)[6]) {
+  const int n[3] = {p->nx, p->ny, p->nz};
+  for (int d = 0; d < 3; ++d) {
+    s0[d] = a.core[2 * d] + (a.core[2 * d] > 0 ? 1 : 0);
+    s1[d] = a.core[2 * d + 1] - (a.core[2 * d + 1] < n[d] ? 1 : 0);
+    if (d == 0 && a.open_lo) s0[d] = std::max(s0[d], 1);          // the planes at an open
+    if (d == 0 && a.open_hi) s1[d] = std::min(s1[d], n[d] - 1);   // face always have a pass 1
+    s0[d] = std::min(std::max(s0[d], 0), n[d]);
+    s1[d] = std::min(std::max(s1[d], s0[d]), n[d]);
+  }
+  std::vector<CellBox> boxes = {
+      {0, s0[0], 0, n[1], 0, n[2]},           {s1[0], n[0], 0, n[1], 0, n[2]},
+      {s0[0], s1[0], 0, s0[1], 0, n[2]},      {s0[0], s1[0], s1[1], n[1], 0, n[2]},
+      {s0[0], s1[0], s0[1], s1[1], 0, s0[2]}, {s0[0], s1[0], s0[1], s1[1], s1[2], n[2]}};
+  for (int m = 0; m < 6; ++m) hole[m] = 0;
+  if (a.nobj > 0) {
+    const CellBox h{std::max(a.hull[0] - 1, s0[0]), std::min(a.hull[1] + 1, s1[0]),
+                    std::max(a.hull[2] - 1, s0[1]), std::min(a.hull[3] + 1, s1[1]),
+                    std::max(a.hull[4] - 1, s0[2]), std::min(a.hull[5] + 1, s1[2])};
+    boxes.push_back(h);
+    if (h.i1 > h.i0 && h.j1 > h.j0 && h.k1 > h.k0) {
+      hole[0] = h.i0; hole[1] = h.i1; hole[2] = h.j0; hole[3] = h.j1; hole[4] = h.k0; hole[5] = h.k1;
+    }
+  }
+  return cell_box_table(boxes, tab);
 }
 
 // Reverse of post(): sources (hard assignments kill the adjoint), then the boundaries that
@@ -170,48 +232,9 @@ int adjoint_cells(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work) {
   const dim3 block(256);
   const CellBoxes whole{};   // (not read by the kernels that cover the whole grid)
   if (a.direct) {
-    // Only cells near a PML slab or an object have a pass 1 (the kernel leaves the others
-    // out cell by cell): launch it over boxes that cover them instead of the whole grid --
-    // six slabs around the part of the PML-free core whose 3x3x3 blocks stay inside it,
-    // and the hull of the objects grown by one cell where it lies in that part.  The boxes
-    // are disjoint: pass 1 has side effects (memory-variable adjoints, object gradients).
-    int s0[3], s1[3];
-    const int n[3] = {p->nx, p->ny, p->nz};
-    for (int d = 0; d < 3; ++d) {
-      s0[d] = a.core[2 * d] + (a.core[2 * d] > 0 ? 1 : 0);
-      s1[d] = a.core[2 * d + 1] - (a.core[2 * d + 1] < n[d] ? 1 : 0);
-      if (d == 0 && a.open_lo) s0[d] = std::max(s0[d], 1);          // the planes at an open
-      if (d == 0 && a.open_hi) s1[d] = std::min(s1[d], n[d] - 1);   // face always have a pass 1
-      s0[d] = std::min(std::max(s0[d], 0), n[d]);
-      s1[d] = std::min(std::max(s1[d], s0[d]), n[d]);
-    }
-    std::vector<CellBox> boxes = {
-        {0, s0[0], 0, n[1], 0, n[2]},           {s1[0], n[0], 0, n[1], 0, n[2]},
-        {s0[0], s1[0], 0, s0[1], 0, n[2]},      {s0[0], s1[0], s1[1], n[1], 0, n[2]},
-        {s0[0], s1[0], s0[1], s1[1], 0, s0[2]}, {s0[0], s1[0], s0[1], s1[1], s1[2], n[2]}};
-    if (a.nobj > 0)
-      boxes.push_back({std::max(a.hull[0] - 1, s0[0]), std::min(a.hull[1] + 1, s1[0]),
-                       std::max(a.hull[2] - 1, s0[1]), std::min(a.hull[3] + 1, s1[1]),
-                       std::max(a.hull[4] - 1, s0[2]), std::min(a.hull[5] + 1, s1[2])});
     CellBoxes tab;
-    tab.count = 0;
-    tab.first[0] = 0;
-    for (const CellBox& b : boxes) {
-      if (b.i1 <= b.i0 || b.j1 <= b.j0 || b.k1 <= b.k0) continue;
-      int gx, gy;
-      box_grid(b, gx, gy);
-      tab.box[tab.count] = b;
-      tab.gx[tab.count] = gx;
-      tab.gy[tab.count] = gy;
-      tab.first[tab.count + 1] = tab.first[tab.count] + (int64_t)gx * gy * (b.i1 - b.i0);
-      ++tab.count;
-    }
-    for (int n = tab.count; n < MAX_CELL_BOXES; ++n) {
-      tab.box[n] = CellBox{0, 0, 0, 0, 0, 0};
-      tab.gx[n] = tab.gy[n] = 1;
-      tab.first[n + 1] = tab.first[tab.count];
-    }
-    if (tab.first[tab.count] >= (1ll << 31)) return fail(-1, "internal: pass 1 of the adjoint over too many workgroups");
+    int s0[3], s1[3], hole[6];
+    if (int rc = adjoint_shell_boxes<T>(p, a, tab, s0, s1, hole)) return rc;
     if (tab.count) {
       const dim3 grid((unsigned)tab.first[tab.count]);
       if (phaseE) hipLaunchKernelGGL((adj_E_cells<T, true, true>), grid, block, 0, p->stream, a, tab);
@@ -246,6 +269,184 @@ int adjoint_gather(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, cons
     if (phaseE) hipLaunchKernelGGL((adj_gather<T, true, false>), grid, block, 0, p->stream, a);
     else hipLaunchKernelGGL((adj_gather<T, false, false>), grid, block, 0, p->stream, a);
   }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- whole reverse steps (yee_adjoint_march.hpp) ---------------------------------------
+// FDTDHIP_ADJ_MARCH: 0 = never, 2 = wherever the plan allows, whatever the grid size (tests);
+// default: large 3-D grids.
+int adjoint_march_mode() {
+  static const int mode = [] {
+    const char* e = getenv("FDTDHIP_ADJ_MARCH");
+    return e ? atoi(e) : 1;
+  }();
+  return mode;
+}
+
+#ifndef FDTDHIP_ADJ_MARCH_TY32
+#define FDTDHIP_ADJ_MARCH_TY32 4   // rows per workgroup of the reverse marching kernel in float32
+#endif
+#ifndef FDTDHIP_ADJ_MARCH_TY64
+#define FDTDHIP_ADJ_MARCH_TY64 4   // the same in float64 (z rows of up to 512 cells)
+#endif
+
+// Whether the reverse sweep of this plan can take whole steps: second adjoint buffers, the
+// plain cells in their direct form (constant materials), nothing that acts on the field
+// adjoints between the half steps (no recorded periodic boundary and hence no PML whose
+// correction follows one; only additive point sources, which have no adjoint of their own),
+// a box of plain cells to march over.
+template <typename T>
+bool adjoint_march_eligible(fdtdhip_plan* p, const AdjArgs<T>& a, const int (&s0)[3], const int (&s1)[3]) {
+  const int mode = adjoint_march_mode();
+  if (mode == 0 || !p->adjE_alt || !p->adjH_alt || !a.direct) return false;
+  for (const PmlH& h : p->pmls)
+    if (!h.lamE_alt || !h.lamH_alt) return false;
+  if (p->H_below || p->E_above) return false;
+  for (const BoundaryRef& b : p->boundaries)
+    if (b.kind == 1) return false;
+  for (const SourceH& s : p->sources)
+    if (s.kind != FDTDHIP_SRC_ADD_POINTS) return false;
+  if (p->nz > 64 * ADJ_MARCH_MAX_WAVES || p->nx / 16 > 65535) return false;
+  for (int d = 0; d < 3; ++d)
+    if (s1[d] - s0[d] < 1) return false;
+  if (mode > 1) return true;
+  const int64_t core = (int64_t)(s1[0] - s0[0]) * (s1[1] - s0[1]) * (s1[2] - s0[2]);
+  return p->nz >= 128 && p->ny >= 64 && p->nx >= 64 && p->cells() >= (1ll << 22) &&
+         core * 2 >= p->cells();
+}
+
+template <typename T, int TY, int MW>
+int launch_adjoint_march_tiles(fdtdhip_plan* p, const AdjArgs<T>& e, const AdjArgs<T>& h, const T* lamE0,
+                               const T* lamH0, T* lamE1, T* lamH1, const int (&s0)[3],
+                               const int (&s1)[3], const int (&hole)[6]) {
+  AdjMarchArgs<T> m;
+  m.lamE0 = lamE0; m.lamH0 = lamH0; m.lamE1 = lamE1; m.lamH1 = lamH1;
+  m.nx = p->nx; m.ny = p->ny; m.nz = p->nz;
+  m.sc = (T)p->sc;
+  for (int c = 0; c < 3; ++c) { m.bgE[c] = e.bg[c]; m.bgH[c] = h.bg[c]; }
+  m.open_lo = e.open_lo; m.open_hi = e.open_hi;
+  for (int d = 0; d < 3; ++d) { m.box[2 * d] = s0[d]; m.box[2 * d + 1] = s1[d]; }
+  for (int n = 0; n < 6; ++n) m.hole[n] = hole[n];
+  const bool holed = hole[1] > hole[0];
+  const int tiles = (s1[1] - s0[1] + TY - 1) / TY, planes = s1[0] - s0[0];
+  const int waves = (p->nz + 63) / 64;
+  void (*kernel)(AdjMarchArgs<T>) = holed ? adj_march_box<T, TY, true, MW> : adj_march_box<T, TY, false, MW>;
+  const int lx = m.lx = march_chunk_planes(planes, tiles, march_slots(p, (const void*)kernel, 64 * waves));
+  m.band = tiles >= 16 ? (tiles + 7) / 8 : 0;
+  m.chunk0 = 0;
+  const dim3 grid(m.band ? 8 * m.band : tiles, (planes + lx - 1) / lx, 1), block(64 * waves);
+  hipLaunchKernelGGL(kernel, grid, block, 0, p->stream, m);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// One whole reverse step, out of place: (lamE0, lamH0) after the step -> (lamE1, lamH1)
+// before it; memory-variable adjoints from one set of arrays to the other (`flip`: 1 first ->
+// second, 2 back).
+//   adj_shell_H over the cells next to PML slabs and objects     lamE1 = lamE0 + ...
+//   adj_march_box over the plain cells                            lamE1, lamH1 of the box
+//   adj_shell_E over the cells next to PML slabs and objects     lamH1 = lamH0 + ...
+//   adj_rescale_absorbing over the box of the objects             lamE1 under absorbing objects
+// The PML faces of a plan as arguments of adj_shell_faces, if the plan qualifies: at most one
+// face per side of an axis, the two faces of an axis apart, and no object next to a slab (so
+// that every cell those launches evaluate has the constant material).
+template <typename T>
+bool adjoint_face_set(const fdtdhip_plan* p, bool phaseE, int flip, const AdjArgs<T>& e, const int (&s0)[3],
+                      const int (&s1)[3], AdjFaceSet<T>& fs) {
+  const int n[3] = {p->nx, p->ny, p->nz};
+  for (int ax = 0; ax < 3; ++ax)
+    for (int side = 0; side < 2; ++side) fs.f[ax][side] = AdjFaceK<T>{nullptr, nullptr, nullptr, nullptr, 0, 0, 1, 1};
+  for (const PmlH& h : p->pmls) {
+    AdjFaceK<T>& f = fs.f[h.axis][h.lo == 0 ? 0 : 1];
+    if (f.t != 0 || !h.fused) return false;
+    T* first = (T*)(phaseE ? h.lamE : h.lamH);
+    T* second = (T*)(phaseE ? h.lamE_alt : h.lamH_alt);
+    f.psi = flip == 1 ? first : second;
+    f.psi_out = flip == 1 ? second : first;
+    f.b = (const T*)(phaseE ? h.bE : h.bH);
+    f.c = (const T*)(phaseE ? h.cE : h.cH);
+    f.lo = h.lo;
+    f.t = h.t;
+    f.sy = h.axis == 1 ? h.t : p->ny;
+    f.sz = h.axis == 2 ? h.t : p->nz;
+  }
+  for (int ax = 0; ax < 3; ++ax)
+    if (fs.f[ax][0].t + fs.f[ax][1].t > n[ax] || (fs.f[ax][0].t && fs.f[ax][0].lo != 0)) return false;
+  if (e.nobj > 0)
+    for (int d = 0; d < 3; ++d)
+      if (e.hull[2 * d] <= s0[d] || e.hull[2 * d + 1] >= s1[d]) return false;
+  return true;
+}
+
+// One whole reverse step, out of place: (lamE0, lamH0) after the step -> (lamE1, lamH1)
+// before it; memory-variable adjoints from one set of arrays to the other (`flip`: 1 first ->
+// second, 2 back).
+//   H half step undone in the cells next to PML slabs and objects     lamE1 = lamE0 + ...
+//   adj_march_box over the plain cells                                 lamE1, lamH1 of the box
+//   E half step undone in the cells next to PML slabs and objects     lamH1 = lamH0 + ...
+//   adj_rescale_absorbing over the box of the objects                  lamE1 under absorbing objects
+// The slabs take adj_shell_faces where the plan qualifies (adjoint_face_set), else the
+// table-walking adj_shell_H / adj_shell_E, which the box around the objects always takes.
+template <typename T>
+int adjoint_march_step(fdtdhip_plan* p, T* lamE0, T* lamH0, T* lamE1, T* lamH1, int flip) {
+  AdjArgs<T> h, e;
+  CellBoxes tab;
+  int s0[3], s1[3], hole[6];
+  // (the boxes of the E half step: objects act in that half step only, but every cell the
+  // marching kernel leaves out needs both half steps undone here)
+  if (int rc = adjoint_args<T>(p, true, lamE1, lamH0, (T*)nullptr, e, flip)) return rc;
+  if (int rc = adjoint_shell_boxes<T>(p, e, tab, s0, s1, hole)) return rc;
+  if (int rc = adjoint_args<T>(p, false, lamE0, lamH0, (T*)nullptr, h, flip)) return rc;
+  static const bool faces_off = [] {
+    const char* v = getenv("FDTDHIP_ADJ_FACES");
+    return v && atoi(v) == 0;
+  }();
+  AdjFaceSet<T> fe, fh;
+  const bool faces = !faces_off && adjoint_face_set<T>(p, true, flip, e, s0, s1, fe) &&
+                     adjoint_face_set<T>(p, false, flip, e, s0, s1, fh);
+  CellBoxes slabs = tab, rest = tab;
+  if (faces) {
+    // the slabs are the first boxes of the table, the box around the objects its last
+    std::vector<CellBox> a, b;
+    const bool holed = hole[1] > hole[0];
+    for (int n = 0; n < tab.count; ++n) (holed && n == tab.count - 1 ? b : a).push_back(tab.box[n]);
+    if (int rc = cell_box_table(a, slabs)) return rc;
+    if (int rc = cell_box_table(b, rest)) return rc;
+  }
+  const dim3 block(256);
+  auto shell = [&](bool phaseE) {
+    const AdjArgs<T>& a = phaseE ? e : h;
+    const T* in = phaseE ? lamH0 : lamE0;
+    T* out = phaseE ? lamH1 : lamE1;
+    if (faces && slabs.count) {
+      const dim3 grid((unsigned)slabs.first[slabs.count]);
+      if (phaseE) hipLaunchKernelGGL((adj_shell_faces<T, true>), grid, block, 0, p->stream, a, fe, in, out, slabs);
+      else hipLaunchKernelGGL((adj_shell_faces<T, false>), grid, block, 0, p->stream, a, fh, in, out, slabs);
+    }
+    if (rest.count) {
+      const dim3 grid((unsigned)rest.first[rest.count]);
+      if (phaseE) hipLaunchKernelGGL((adj_shell_E<T>), grid, block, 0, p->stream, a, in, out, rest);
+      else hipLaunchKernelGGL((adj_shell_H<T>), grid, block, 0, p->stream, a, in, out, rest);
+    }
+  };
+  shell(false);
+  if ((p->nz + 63) / 64 <= 8) {
+    if (int rc = launch_adjoint_march_tiles<T, sizeof(T) == 4 ? FDTDHIP_ADJ_MARCH_TY32 : FDTDHIP_ADJ_MARCH_TY64, 8>(
+            p, e, h, lamE0, lamH0, lamE1, lamH1, s0, s1, hole))
+      return rc;
+  } else {
+    if (int rc = launch_adjoint_march_tiles<T, sizeof(T) == 4 ? FDTDHIP_ADJ_MARCH_TY32 : 2, ADJ_MARCH_MAX_WAVES>(
+            p, e, h, lamE0, lamH0, lamE1, lamH1, s0, s1, hole))
+      return rc;
+  }
+  shell(true);
+  bool absorbing = false;
+  for (const ObjH& o : p->objs) absorbing |= o.kind == FDTDHIP_OBJ_ABSORBING;
+  const int64_t hull = (int64_t)std::max(e.hull[1] - e.hull[0], 0) * std::max(e.hull[3] - e.hull[2], 0) *
+                       std::max(e.hull[5] - e.hull[4], 0);
+  if (absorbing && hull > 0)
+    hipLaunchKernelGGL((adj_rescale_absorbing<T>), dim3(blocks_for(hull)), block, 0, p->stream, e, lamE1);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -313,14 +514,46 @@ int adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH, void* w
     p->trace_cursor = -1;
     return 0;
   }
-  for (int64_t s = nsteps - 1; s >= 0; --s) {
+  int64_t s = nsteps - 1;
+  auto two_pass_step = [&]() -> int {
     p->trace_cursor = s;
     for (int phase = 0; phase < 2; ++phase) {  // undo the H half step, then the E half step
       if (int rc = adjoint_cells<T>(p, phase == 1, (T*)lamE, (T*)lamH, (T*)work)) return rc;
       if (int rc = adjoint_gather<T>(p, phase == 1, (T*)lamE, (T*)lamH, (T*)work, (const T*)nullptr))
         return rc;
     }
+    return 0;
+  };
+  {
+    // whole reverse steps in pairs, first -> second adjoint buffers and back, so that the
+    // result ends in the caller's arrays; with an odd count the last recorded step is undone
+    // in the two-pass form first
+    AdjArgs<T> a;
+    CellBoxes tab;
+    int s0[3], s1[3], hole[6];
+    p->trace_cursor = s;
+    if (int rc = sync_obj_table<T>(p)) return rc;
+    if (int rc = adjoint_args<T>(p, true, (T*)lamE, (T*)lamH, (T*)work, a)) return rc;
+    if (int rc = adjoint_shell_boxes<T>(p, a, tab, s0, s1, hole)) return rc;
+    if (adjoint_march_eligible<T>(p, a, s0, s1)) {
+      if (nsteps % 2) {
+        if (int rc = two_pass_step()) return rc;
+        --s;
+      }
+      for (; s >= 1; s -= 2) {
+        p->trace_cursor = s;
+        if (int rc = adjoint_march_step<T>(p, (T*)lamE, (T*)lamH, (T*)p->adjE_alt, (T*)p->adjH_alt, 1))
+          return rc;
+        p->trace_cursor = s - 1;
+        if (int rc = adjoint_march_step<T>(p, (T*)p->adjE_alt, (T*)p->adjH_alt, (T*)lamE, (T*)lamH, 2))
+          return rc;
+      }
+      p->trace_cursor = -1;
+      return 0;
+    }
   }
+  for (; s >= 0; --s)
+    if (int rc = two_pass_step()) return rc;
   p->trace_cursor = -1;
   return 0;
 }

@@ -78,6 +78,8 @@ struct PmlH {
   void* psiE_alt = nullptr; // second psiE buffer of the fused full step
   void* lamE = nullptr;     // adjoints of psiE / psiH (differentiable runs)
   void* lamH = nullptr;
+  void* lamE_alt = nullptr; // second adjoint arrays of whole reverse steps
+  void* lamH_alt = nullptr;
 };
 
 struct BoundaryRef {
@@ -191,6 +193,7 @@ struct fdtdhip_plan {
   // 1: built, -1: not possible (shared cells, too many detectors or points)
   int32_t* detmap = nullptr;
   int detmap_state = 0;
+  void *adjE_alt = nullptr, *adjH_alt = nullptr;   // second adjoint fields of whole reverse steps
   void* adj_work = nullptr;   // second `work` array of the paired adjoint launches (owned)
   int64_t adj_work_bytes = 0;
   int64_t trace_cursor = -1;  // row of the curl traces the next E half step writes; -1: no traces
@@ -274,8 +277,10 @@ int sync_obj_table(fdtdhip_plan* p) {
 
 // Which PML descriptor table a kernel reads: the two half steps in place, the E half
 // of the fused full step in its two directions (first -> second psi_E buffer and
-// back), and the adjoint half steps (psi -> adjoint arrays).
-enum PmlTab { TAB_E = 0, TAB_H, TAB_E_AB, TAB_E_BA, TAB_ADJ_E, TAB_ADJ_H, TAB_COUNT };
+// back), the adjoint half steps (psi -> adjoint arrays) in place, and from the first to the
+// second adjoint arrays and back (whole reverse steps).
+enum PmlTab { TAB_E = 0, TAB_H, TAB_E_AB, TAB_E_BA, TAB_ADJ_E, TAB_ADJ_H,
+              TAB_ADJ_E_AB, TAB_ADJ_E_BA, TAB_ADJ_H_AB, TAB_ADJ_H_BA, TAB_COUNT };
 
 template <typename T>
 PmlK<T> make_pmlk(const fdtdhip_plan* p, const PmlH& h, bool phaseE);
@@ -305,6 +310,15 @@ int sync_pml_tables(fdtdhip_plan* p) {
     ah.psi = ah.psi_out = (T*)h.lamH;
     host[TAB_ADJ_E * MAX_PML + i] = ae;
     host[TAB_ADJ_H * MAX_PML + i] = ah;
+    PmlK<T> eab = ae, eba = ae, hab = ah, hba = ah;
+    eab.psi_out = (T*)h.lamE_alt;
+    eba.psi = (T*)h.lamE_alt;
+    hab.psi_out = (T*)h.lamH_alt;
+    hba.psi = (T*)h.lamH_alt;
+    host[TAB_ADJ_E_AB * MAX_PML + i] = eab;
+    host[TAB_ADJ_E_BA * MAX_PML + i] = eba;
+    host[TAB_ADJ_H_AB * MAX_PML + i] = hab;
+    host[TAB_ADJ_H_BA * MAX_PML + i] = hba;
   }
   if (int rc = upload_table(p, p->pml_tables, host.data(), bytes)) return rc;
   p->pml_dirty = false;

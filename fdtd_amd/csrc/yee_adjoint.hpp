@@ -277,7 +277,10 @@ __device__ __forceinline__ void adj_gather_direct(const AdjArgs<T>& a, int i, in
 // adjoint of the cell's E before the half step.  store = false evaluates the cell without
 // side effects (memory-variable adjoints, object gradients), for a lane that needs a
 // neighbour's G.  Returns whether lam changed (only absorbing objects rescale it).
-template <typename T>
+// ONLY_AXIS >= 0: only the entries of G for differences along that axis are wanted (a lane
+// evaluating a neighbour it gathers from): PML faces normal to the other axes add to other
+// entries and are left out.
+template <typename T, int ONLY_AXIS = -1>
 __device__ __forceinline__ bool adj_E_cell(const AdjArgs<T>& a, int i, int j, int k, int64_t c3,
                                            T lam[3], T G[6], bool store) {
   T m[3];
@@ -292,6 +295,7 @@ __device__ __forceinline__ bool adj_E_cell(const AdjArgs<T>& a, int i, int j, in
   for (int q = 0; q < MAX_PML; ++q) {   // last registered first
     const int p = MAX_PML - 1 - q;
     if (p >= a.npml) continue;
+    if (ONLY_AXIS >= 0 && a.face_axis[p] != ONLY_AXIS) continue;
     if (!adj_face_touched(a, p, i, j, k)) continue;
     const PmlK<T> P = a.pml[p];
     if (P.axis == 0) adj_pml_face<T, 0>(P, a.nx, i, j, k, true, a.sc, lam, m, G[WX_Y], G[WX_Z], store);
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(256) void adj_E_cells(AdjArgs<T> a, CellBoxes box) 
 }
 
 // The same for the H half step (no objects act in that half step).
-template <typename T>
+template <typename T, int ONLY_AXIS = -1>
 __device__ __forceinline__ void adj_H_cell(const AdjArgs<T>& a, int i, int j, int k, int64_t c3,
                                            const T lam[3], T G[6], bool store) {
   T m[3];
@@ -413,6 +417,7 @@ __device__ __forceinline__ void adj_H_cell(const AdjArgs<T>& a, int i, int j, in
   for (int q = 0; q < MAX_PML; ++q) {   // last registered first
     const int p = MAX_PML - 1 - q;
     if (p >= a.npml) continue;
+    if (ONLY_AXIS >= 0 && a.face_axis[p] != ONLY_AXIS) continue;
     if (!adj_face_touched(a, p, i, j, k)) continue;
     const PmlK<T> P = a.pml[p];
     if (P.axis == 0) adj_pml_face<T, 0>(P, a.nx, i, j, k, false, a.sc, lam, m, G[WX_Y], G[WX_Z], store);

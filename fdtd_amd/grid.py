@@ -516,11 +516,37 @@ class Grid:
         that one half step alone: per-cell pass, then the gather (see ``fdtd_amd/autograd.py``)."""
         p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         if half is None:
-            _lib.check(lib.fdtdhip_adjoint_run(self._plan, n, p(lamE), p(lamH), p(work)))
+            # second adjoint fields let the library undo whole steps in one pass over the
+            # cells away from PMLs and objects (large 3-D grids; FDTDHIP_ADJ_MARCH=2: any)
+            alt = None
+            if self._adjoint_second_buffers and n >= 2 and (
+                    self._adjoint_march_forced() or self.Nx * self.Ny * self.Nz >= 1 << 22):
+                alt = (torch.empty_like(lamE), torch.empty_like(lamH))
+            _lib.check(lib.fdtdhip_plan_set_adjoint_buffers(
+                self._plan, p(alt[0]) if alt else None, p(alt[1]) if alt else None))
+            pmls = [b for b in self.boundaries if hasattr(b, "thickness") and b._active] if alt else []
+            psi_alt = [(torch.empty_like(b._psiE.detach()), torch.empty_like(b._psiH.detach())) for b in pmls]
+            for b, (ae, ah) in zip(pmls, psi_alt):
+                _lib.check(lib.fdtdhip_plan_set_pml_adjoint_buffers(self._plan, b._native_id, p(ae), p(ah)))
+            try:
+                _lib.check(lib.fdtdhip_adjoint_run(self._plan, n, p(lamE), p(lamH), p(work)))
+            finally:
+                if alt:
+                    _lib.check(lib.fdtdhip_plan_set_adjoint_buffers(self._plan, None, None))
+                for b in pmls:
+                    _lib.check(lib.fdtdhip_plan_set_pml_adjoint_buffers(self._plan, b._native_id, None, None))
             return
         phase = 1 if half == "E" else 0
         _lib.check(lib.fdtdhip_adjoint_cells(self._plan, phase, 0, p(lamE), p(lamH), p(work)))
         _lib.check(lib.fdtdhip_adjoint_gather(self._plan, phase, p(lamE), p(lamH), p(work), None))
+
+    _adjoint_second_buffers = True   # (tests switch it off to obtain the two-pass sweep)
+
+    @staticmethod
+    def _adjoint_march_forced():
+        import os
+
+        return os.environ.get("FDTDHIP_ADJ_MARCH") == "2"
 
     def _provide_step_buffers(self, slab=False):
         """Second E/H (and PML psi_E) buffers that let ``run`` use the fused full-step

@@ -319,6 +319,21 @@ int fdtdhip_plan_set_object_grad(fdtdhip_plan* plan, int id, void* grad);
 int fdtdhip_plan_set_object_modifier(fdtdhip_plan* plan, int id, const void* weights,
                                      void* energy_trace, void* grad_weights);
 int fdtdhip_plan_set_pml_adjoint(fdtdhip_plan* plan, int id, void* lam_psiE, void* lam_psiH);
+
+/* Second adjoint arrays for whole reverse steps (no reference counterpart: torch autograd
+ * walks the reference's tape one slice operation at a time, fdtd/grid.py:275-325).  With
+ * lamE_alt / lamH_alt (device arrays shaped like lamE / lamH) and, for every PML,
+ * lam_psiE_alt / lam_psiH_alt (shaped like its lam_psiE / lam_psiH), contents scratch, a plan
+ * whose materials are proven constants, without periodic boundary and with additive point
+ * sources only, undoes a step out of place, first -> second arrays: one marching pass over
+ * the cells away from PML slabs and objects -- one read and one write of each adjoint field
+ * -- and one pass per half step over the cells next to them, without the `work` array.
+ * fdtdhip_adjoint_run then walks pairs of steps, first -> second arrays and back (an odd
+ * first one in the two-pass form), and its results equal those without second arrays.
+ * NULL withdraws them.  FDTDHIP_ADJ_MARCH=0 in the environment keeps the two-pass form. */
+int fdtdhip_plan_set_adjoint_buffers(fdtdhip_plan* plan, void* lamE_alt, void* lamH_alt);
+int fdtdhip_plan_set_pml_adjoint_buffers(fdtdhip_plan* plan, int id, void* lam_psiE_alt,
+                                         void* lam_psiH_alt);
 int fdtdhip_adjoint_run(fdtdhip_plan* plan, int64_t nsteps, void* lamE, void* lamH, void* work);
 
 /* fdtdhip_adjoint_run for callers that cannot allocate device memory: tight serving /
