@@ -36,7 +36,8 @@ struct AdjMarchArgs {
   const T* lamH0;   // adjoint of H after it
   T* lamE1;         // adjoint of E before the step; cells outside the box / inside the hole:
                     // read only (adj_shell_H wrote them)
-  T* lamH1;         // adjoint of H before the step
+  T* lamH1;         // adjoint of H before the step (inside the hole: scratch, overwritten by
+                    // adj_shell_E after this launch)
   int nx, ny, nz;
   T sc;
   T bgE[3], bgH[3];   // the constant inverse permittivity / permeability
@@ -94,13 +95,10 @@ __global__ __launch_bounds__(64 * MW) void adj_march_box(AdjMarchArgs<T> a) {
   // new lamE (components x, y) of each wave's first lane, for the last lane of the wave before
   __shared__ T xch[2][ADJ_MARCH_MAX_WAVES + 1][TY][2];
   T Hp[TY + 1][3], Ep[TY + 1][3];
-  bool holedp[TY + 1];
 #pragma unroll
-  for (int r = 0; r <= TY; ++r) {
-    holedp[r] = false;
+  for (int r = 0; r <= TY; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) { Hp[r][c] = T(0); Ep[r][c] = T(0); }
-  }
   if (i0 > 0 && zin) {
 #pragma unroll
     for (int r = 0; r <= TY; ++r) {
@@ -114,52 +112,49 @@ __global__ __launch_bounds__(64 * MW) void adj_march_box(AdjMarchArgs<T> a) {
   const bool hasz = k > 0, hasz1 = k < nz - 1;
   const T zero = T(0);
   for (int i = i0; i <= i1; ++i) {
-    T Hc[TY + 1][3], En[TY + 1][3];
+    T Hc[TY + 1][3], En[TY + 1][3], zx[TY + 1], zy[TY + 1], ux = T(0), uz = T(0);
 #pragma unroll
-    for (int r = 0; r <= TY; ++r)
+    for (int r = 0; r <= TY; ++r) {
+      zx[r] = zy[r] = T(0);
 #pragma unroll
       for (int c = 0; c < 3; ++c) { Hc[r][c] = T(0); En[r][c] = T(0); }
+    }
     const bool plane = i < nx;
     const bool pin = i < bx1;      // a plane of the box (else the plane past it, if any)
     bool holed[TY + 1];            // rows of this plane that cross the hole
 #pragma unroll
     for (int r = 0; r <= TY; ++r)
       holed[r] = HAS_HOLE && i >= a.hole[0] && i < a.hole[1] && j0 + r >= a.hole[2] && j0 + r < a.hole[3];
-    if (plane && (zin || zedge)) {
-      const int64_t pbase = (int64_t)i * sx + 3 * k;
-      T zx[TY + 1], zy[TY + 1], ux = T(0), uz = T(0);
-      // every load of the plane is requested before the first one is used
+    // Every load of the plane in ONE batch: no test per row around the loads (with one, the
+    // compiler closes each row's block with copies of what it loaded and waits for them, a
+    // round trip per row).  Rows and planes that do not exist are clamped to ones that do and
+    // what they deliver is never used: every use below is masked.  A cell outside the box or
+    // inside the hole delivers its new lamE from the second buffer, where adj_shell_H has put
+    // it, chosen by address.
+    if (zin || zedge) {
+      const int64_t pbase = (int64_t)min(i, nx - 1) * sx + 3 * k;
 #pragma unroll
       for (int r = 0; r <= TY; ++r) {
-        const int j = j0 + r;
-        zx[r] = zy[r] = T(0);
-        const int64_t c3 = pbase + (int64_t)j * sy;
-        if (pin && zin && j < by1) {
-          Hc[r][0] = H0[c3]; Hc[r][1] = H0[c3 + 1]; Hc[r][2] = H0[c3 + 2];
-          if (zhole && holed[r]) {
-            En[r][0] = E1r[c3]; En[r][1] = E1r[c3 + 1]; En[r][2] = E1r[c3 + 2];
-          } else {
-            En[r][0] = E0[c3]; En[r][1] = E0[c3 + 1]; En[r][2] = E0[c3 + 2];
-            const T* z = H0 + (hasz ? c3 - 3 : c3);
-            zx[r] = z[0]; zy[r] = z[1];
-          }
-        } else if (j < ny && ((j < by1 && r < TY) || (pin && zin && j == by1))) {
-          // outside the box next to a cell of the tile: along x (the plane past the box),
-          // along y (the row past it) or along z (the cell past it) -- the new lamE that
-          // adj_shell_H left in the second buffer
-          En[r][0] = E1r[c3]; En[r][1] = E1r[c3 + 1]; En[r][2] = E1r[c3 + 2];
-        }
+        const int64_t c3 = pbase + (int64_t)min(j0 + r, ny - 1) * sy;
+        const bool mine = pin && zin && j0 + r < by1 && !(zhole && holed[r]);
+        const T* e = mine ? E0 : E1r;
+        Hc[r][0] = H0[c3]; Hc[r][1] = H0[c3 + 1]; Hc[r][2] = H0[c3 + 2];
+        En[r][0] = e[c3]; En[r][1] = e[c3 + 1]; En[r][2] = e[c3 + 2];
+        const T* z = H0 + (hasz ? c3 - 3 : c3);
+        zx[r] = z[0]; zy[r] = z[1];
       }
-      if (pin && zin && j0 > 0) {
-        const T* u = H0 + pbase + (int64_t)(j0 - 1) * sy;
-        ux = u[0]; uz = u[2];
-      }
+      const T* u = H0 + pbase + (int64_t)max(j0 - 1, 0) * sy;
+      ux = u[0]; uz = u[2];
+    }
+    if (plane && (zin || zedge)) {
+      const int64_t pbase = (int64_t)i * sx + 3 * k;
       const bool ox = i > 0;
       if (pin && zin) {
 #pragma unroll
         for (int r = 0; r <= TY; ++r) {
           const int j = j0 + r;
-          if (j >= by1 || (zhole && holed[r])) continue;
+          if (j >= by1) continue;
+          const bool keep = zhole && holed[r];   // a cell of the hole: lamE1 as loaded
           const int64_t c3 = pbase + (int64_t)j * sy;
           const bool oy = j > 0;
           // undo the H half step at (i, j, k): gather from the cell and its three low neighbours
@@ -176,7 +171,8 @@ __global__ __launch_bounds__(64 * MW) void adj_march_box(AdjMarchArgs<T> a) {
           add[1] = ((ox ? gx[WX_Y] : zero) - g[WX_Y]) + ((hasz ? gz[WZ_Y] : zero) - g[WZ_Y]);
           add[2] = ((ox ? gx[WX_Z] : zero) - g[WX_Z]) + ((oy ? gy[WY_Z] : zero) - g[WY_Z]);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) En[r][c] = En[r][c] + add[c];
+          for (int c = 0; c < 3; ++c) En[r][c] = keep ? En[r][c] : En[r][c] + add[c];
+          // (a cell of the hole stores the value it loaded back: no lane-dependent branch)
           if (r < TY && i < i1) {
             T* o = a.lamE1 + c3;
             __builtin_nontemporal_store(En[r][0], o);
@@ -195,7 +191,9 @@ __global__ __launch_bounds__(64 * MW) void adj_march_box(AdjMarchArgs<T> a) {
         // new lamE of the cell after this one: the next lane's, or the next wave's first lane
         T ax = __shfl_down(Ep[r][0], 1), ay = __shfl_down(Ep[r][1], 1);
         if (lane == 63) { ax = xch[(i - 1) & 1][w + 1][r][0]; ay = xch[(i - 1) & 1][w + 1][r][1]; }
-        if (zin && j < by1 && !(zhole && holedp[r])) {
+        // (cells of the hole included: adj_shell_E, which follows this launch, overwrites
+        // them -- a test per row here cost 10 % of the launch)
+        if (zin && j < by1) {
           const bool oy1 = j < ny - 1;
           // undo the E half step at (i-1, j, k): gather from the cell and its three high neighbours
           const T vx[3] = {zero, En[r][1], En[r][2]};
@@ -219,11 +217,9 @@ __global__ __launch_bounds__(64 * MW) void adj_march_box(AdjMarchArgs<T> a) {
       }
     }
 #pragma unroll
-    for (int r = 0; r <= TY; ++r) {
-      holedp[r] = holed[r];
+    for (int r = 0; r <= TY; ++r)
 #pragma unroll
       for (int c = 0; c < 3; ++c) { Hp[r][c] = Hc[r][c]; Ep[r][c] = En[r][c]; }
-    }
     if (lane == 0) {
 #pragma unroll
       for (int r = 0; r < TY; ++r) { xch[i & 1][w][r][0] = En[r][0]; xch[i & 1][w][r][1] = En[r][1]; }
