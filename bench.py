@@ -35,7 +35,9 @@ Extra objects in the JSON line:
   also          (one GPU, default workload, unless --no-also) the other benchmark
                 configurations measured by the same run: the headline grid with both material
                 arrays read, the headline grid over 1000 steps ("sustained"), m3, m2, m3v64, m4,
-                and a differentiable run with its reverse sweep ("adjoint")
+                differentiable runs with their reverse sweeps ("adjoint" at 256^3, "adjoint_512",
+                "m5": the reference's learnable_focus set-up in one autograd node and one node
+                per step) and the README example ("c1", steps per second)
 """
 
 import argparse
@@ -302,25 +304,55 @@ def measure_single(workload, steps, warmup, materials="auto"):
     return rec
 
 
-def measure_adjoint():
-    """configs[4] in the size of the other legs: a differentiable run (256^3 float32, six PMLs,
-    a learnable 64^3 anisotropic box, 40 steps recorded in one autograd node) and its reverse
-    sweep; milliseconds per step of each (tools/bench_adjoint.py, workload `large`)."""
+def measure_adjoint(kind="large", passes=2):
+    """configs[4]: a differentiable run recorded in one autograd node and its reverse sweep;
+    milliseconds per step of each (tools/bench_adjoint.py).  `large`: 256^3 float32, six PMLs,
+    a learnable 64^3 anisotropic box, in the size of the other legs; `xlarge`: the same at
+    512^3; `small`: the 97x97x1 float64 set-up of the reference's examples/learnable_focus.py:98-128,
+    200 steps; `stepwise`: that set-up advanced one step per autograd node, as the reference's
+    cortical/autoencoder.py:108-112 drives the grid."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_adjoint
 
     best = None
-    for _ in range(2):      # the first pass warms up allocator and code objects
-        r = bench_adjoint.once("large")
+    for _ in range(passes):      # the first pass warms up allocator and code objects
+        r = bench_adjoint.once(kind)
         if best is None or r["forward_ms_per_step"] + r["backward_ms_per_step"] < \
                 best["forward_ms_per_step"] + best["backward_ms_per_step"]:
             best = r
-    return {"workload": "256x256x256 f32 6xPML(10) + learnable anisotropic 64^3, 40 steps forward "
-                        "(curl traces recorded) and backward (reverse-time adjoint)",
-            "forward_ms_per_step": round(best["forward_ms_per_step"], 4),
-            "backward_ms_per_step": round(best["backward_ms_per_step"], 4),
-            "forward_Gcells_s": round(best["forward_Gcells_s"], 2),
-            "backward_Gcells_s": round(best["backward_Gcells_s"], 2), "unit": "Gcells/s"}
+    what = {"large": "256x256x256 f32 6xPML(10) + learnable anisotropic 64^3",
+            "xlarge": "512x512x512 f32 6xPML(10) + learnable anisotropic 64^3",
+            "small": "97x97x1 f64 periodic z + learnable anisotropic 40x20 (learnable_focus set-up), one autograd node",
+            "stepwise": "97x97x1 f64 periodic z + learnable anisotropic 40x20 (learnable_focus set-up), "
+                        "one autograd node per step"}[kind]
+    return {"workload": f"{what}, {best['steps']} steps forward (curl traces recorded) and backward "
+                        "(reverse-time adjoint)",
+            "forward_ms_per_step": round(best["forward_ms_per_step"], 5),
+            "backward_ms_per_step": round(best["backward_ms_per_step"], 5),
+            "forward_Gcells_s": round(best["forward_Gcells_s"], 3),
+            "backward_Gcells_s": round(best["backward_Gcells_s"], 3), "unit": "Gcells/s"}
+
+
+def measure_c1(steps=5000, warmup=500):
+    """configs[0] on the GPU: the README example (reference README.md:137-296), launch-bound;
+    steps per second without per-launch events."""
+    import torch
+
+    import fdtd_amd as fdtd
+
+    grid, cells, _, dt, desc = build_workload(fdtd, "c1")
+    with torch_no_grad():
+        grid.run(warmup, progress_bar=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        grid.run(steps, progress_bar=False)
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    del grid
+    return {"workload": desc, "name": "c1", "dtype": dt, "steps": steps, "warmup": warmup,
+            "steps_per_s": round(steps / elapsed, 1), "us_per_step": round(elapsed / steps * 1e6, 3),
+            "value": round(cells * steps / elapsed / 1e9, 4), "unit": "Gcells/s",
+            "kernel": "one-lane-per-cell whole-step kernel, one launch per step"}
 
 
 def cpu_baseline(name, budget_s=12.0):
@@ -401,6 +433,12 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # under rocprofv3 the profiler's preloaded library has initialised the GPU already, and
+        # starting the ranks from here would be a program started by a process that holds it
+        preload = os.environ.get("LD_PRELOAD", "")
+        if "rocprof" in preload.lower() or any(k.startswith("ROCPROF_") for k in os.environ):
+            sys.exit("bench.py --gpus N does not start its own ranks under a profiler: profile one rank "
+                     "(--gpus 1) or start the ranks with torch.distributed.run and profile from outside")
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
@@ -532,7 +570,10 @@ def main():
         also["m2"] = measure_single("m2", 1000, 20)
         also["m3v64"] = measure_single("m3v64", 100, 10)
         also["m4"] = measure_single("m4", 100, 10)     # one GPU's share of the 8-GPU configuration
-        also["adjoint"] = measure_adjoint()
+        also["adjoint"] = measure_adjoint("large")
+        also["adjoint_512"] = measure_adjoint("xlarge")
+        also["c1"] = measure_c1()
+        also["m5"] = {"one_node": measure_adjoint("small", 3), "node_per_step": measure_adjoint("stepwise", 3)}
         out["also"] = also
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

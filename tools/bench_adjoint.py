@@ -6,8 +6,8 @@ small    97x97x1 float64, periodic z, point source, learnable 40x20 box, 200 ste
          and backward in one autograd node (the learnable_focus set-up)
 stepwise the same, advanced one step per autograd node (how reference
          cortical/autoencoder.py:108-109 drives the grid)
-large    256^3 float32, 6 PML(10), learnable 64^3 box, 40 steps forward and backward
-xlarge   the same at 512^3, 20 steps
+large    256^3 float32, 6 PML(10), learnable 64^3 box, 100 steps forward and backward
+xlarge   the same at 512^3, 40 steps
 plane2d  3000x3000x1 float32, 4 PML(10), learnable 64x64 box, 40 steps
 Prints one JSON line per workload: milliseconds per step for forward and for backward.
 """
@@ -50,7 +50,7 @@ def build(kind):
             g[tuple(hi)] = fdtd.PML()
         g[256, 180, 256] = fdtd.PointSource(period=20)
         g[224:288, 224:288, 224:288] = fdtd.LearnableAnisotropicObject(permittivity=2.5)
-        return g, 20, (slice(240, 272), 330, slice(240, 272))
+        return g, 40, (slice(240, 272), 330, slice(240, 272))
     g = fdtd.Grid((256, 256, 256))
     for axis in range(3):
         lo, hi = [slice(None)] * 3, [slice(None)] * 3
@@ -59,7 +59,7 @@ def build(kind):
         g[tuple(hi)] = fdtd.PML()
     g[128, 90, 128] = fdtd.PointSource(period=20)
     g[96:160, 96:160, 96:160] = fdtd.LearnableAnisotropicObject(permittivity=2.5)
-    return g, 40, (slice(120, 136), 110, slice(120, 136))
+    return g, 100, (slice(120, 136), 110, slice(120, 136))
 
 
 def once(kind):

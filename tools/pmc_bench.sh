@@ -5,6 +5,7 @@
 set -e
 cd "$(dirname "$0")/.."
 w=$1; shift
+case " $* " in *" --gpus "*) echo "profile one rank only: --gpus is not accepted here" >&2; exit 2;; esac
 out=gpurun_out/pmc_$w
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp

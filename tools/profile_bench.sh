@@ -4,6 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 tag=$1; shift
+case " $* " in *" --gpus "*) echo "profile one rank only: --gpus is not accepted here" >&2; exit 2;; esac
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
