@@ -50,9 +50,6 @@ int fdtdhip_plan_destroy(fdtdhip_plan* p) {
     release_tables(p);
     if (p->pml_tables) (void)hipFree(p->pml_tables);
     if (p->scan_flag) (void)hipFree(p->scan_flag);
-    if (p->side_fork) (void)hipEventDestroy(p->side_fork);
-    if (p->side_join) (void)hipEventDestroy(p->side_join);
-    if (p->side) (void)hipStreamDestroy(p->side);
     for (int n = 0; n < StagingRing::SLOTS; ++n) {
       if (p->staging.done[n]) (void)hipEventDestroy(p->staging.done[n]);
       if (p->staging.host[n]) (void)hipHostFree(p->staging.host[n]);

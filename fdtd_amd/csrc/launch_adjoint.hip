@@ -385,11 +385,12 @@ bool adjoint_face_set(const fdtdhip_plan* p, bool phaseE, int flip, const AdjArg
 //   H half step undone in the cells next to PML slabs and objects     lamE1 = lamE0 + ...
 //   adj_march_box over the plain cells                                 lamE1, lamH1 of the box
 //   E half step undone in the cells next to PML slabs and objects     lamH1 = lamH0 + ...
-//   adj_rescale_absorbing over the box of the objects                  lamE1 under absorbing objects
-// The slabs take adj_shell_faces where the plan qualifies (adjoint_face_set), else the
-// table-walking adj_shell_H / adj_shell_E, which the box around the objects always takes.
+// Where the plan qualifies (adjoint_face_set) the slabs take adj_shell_faces and the box around
+// the objects the two passes through `work` (adj_E_cells, adj_shell_gather);
+// otherwise all of them take the table-walking adj_shell_H / adj_shell_E and
+// adj_rescale_absorbing rescales lamE1 under absorbing objects afterwards.
 template <typename T>
-int adjoint_march_step(fdtdhip_plan* p, T* lamE0, T* lamH0, T* lamE1, T* lamH1, int flip) {
+int adjoint_march_step(fdtdhip_plan* p, T* lamE0, T* lamH0, T* lamE1, T* lamH1, T* work, int flip) {
   AdjArgs<T> h, e;
   CellBoxes tab;
   int s0[3], s1[3], hole[6];
@@ -419,41 +420,38 @@ int adjoint_march_step(fdtdhip_plan* p, T* lamE0, T* lamH0, T* lamE1, T* lamH1, 
   for (const ObjH& o : p->objs) absorbing |= o.kind == FDTDHIP_OBJ_ABSORBING;
   const int64_t hull = (int64_t)std::max(e.hull[1] - e.hull[0], 0) * std::max(e.hull[3] - e.hull[2], 0) *
                        std::max(e.hull[5] - e.hull[4], 0);
-  // The box around the objects is small and its launches are chains of dependent round trips
-  // (256^3 with a 64^3 box: 35 + 9 us of a 0.36 ms step): they run beside the slab launches, on
-  // a stream of the plan's own, forked and joined by events.
-  const bool beside = faces && slabs.count && rest.count && !p->no_alloc;
-  if (beside && !p->side) {
-    HIPCHK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&p->side_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&p->side_join, hipEventDisableTiming));
-  }
   auto shell = [&](bool phaseE) -> int {
     const AdjArgs<T>& a = phaseE ? e : h;
     const T* in = phaseE ? lamH0 : lamE0;
     T* out = phaseE ? lamH1 : lamE1;
+    // (the launches over the box around the objects on a second stream, beside those over
+    // the slabs, were measured: both slowed down, 0.36 against 0.33 ms per reverse step at
+    // 256^3 with a 64^3 box, no difference at 512^3)
     hipStream_t rest_stream = p->stream;
-    if (beside) {
-      HIPCHK(hipEventRecord(p->side_fork, p->stream));
-      HIPCHK(hipStreamWaitEvent(p->side, p->side_fork, 0));
-      rest_stream = p->side;
-    }
     if (faces && slabs.count) {
       const dim3 grid((unsigned)slabs.first[slabs.count]);
       if (phaseE) hipLaunchKernelGGL((adj_shell_faces<T, true>), grid, block, 0, p->stream, a, fe, in, out, slabs);
       else hipLaunchKernelGGL((adj_shell_faces<T, false>), grid, block, 0, p->stream, a, fh, in, out, slabs);
     }
-    if (rest.count) {
+    if (rest.count && faces) {
+      // the box around the objects alone (no PML slab near it): two passes in the E half step,
+      // none but the gather in the H half step, where all of its cells are plain
+      const dim3 grid((unsigned)rest.first[rest.count]);
+      AdjArgs<T> w = a;
+      w.work = work;
+      if (phaseE) {
+        hipLaunchKernelGGL((adj_E_cells<T, true, true>), grid, block, 0, rest_stream, w, rest);
+        hipLaunchKernelGGL((adj_shell_gather<T, true>), grid, block, 0, rest_stream, w, in, out, rest);
+      } else {
+        hipLaunchKernelGGL((adj_shell_gather<T, false>), grid, block, 0, rest_stream, w, in, out, rest);
+      }
+    } else if (rest.count) {
       const dim3 grid((unsigned)rest.first[rest.count]);
       if (phaseE) hipLaunchKernelGGL((adj_shell_E<T>), grid, block, 0, rest_stream, a, in, out, rest);
       else hipLaunchKernelGGL((adj_shell_H<T>), grid, block, 0, rest_stream, a, in, out, rest);
-    }
-    // (lamE1 under absorbing objects: once every lane of adj_shell_E has read it)
-    if (phaseE && absorbing && hull > 0)
-      hipLaunchKernelGGL((adj_rescale_absorbing<T>), dim3(blocks_for(hull)), block, 0, rest_stream, e, lamE1);
-    if (beside) {
-      HIPCHK(hipEventRecord(p->side_join, p->side));
-      HIPCHK(hipStreamWaitEvent(p->stream, p->side_join, 0));
+      // (lamE1 under absorbing objects: once every lane of adj_shell_E has read it)
+      if (phaseE && absorbing && hull > 0)
+        hipLaunchKernelGGL((adj_rescale_absorbing<T>), dim3(blocks_for(hull)), block, 0, rest_stream, e, lamE1);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -562,10 +560,10 @@ int adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH, void* w
       }
       for (; s >= 1; s -= 2) {
         p->trace_cursor = s;
-        if (int rc = adjoint_march_step<T>(p, (T*)lamE, (T*)lamH, (T*)p->adjE_alt, (T*)p->adjH_alt, 1))
+        if (int rc = adjoint_march_step<T>(p, (T*)lamE, (T*)lamH, (T*)p->adjE_alt, (T*)p->adjH_alt, (T*)work, 1))
           return rc;
         p->trace_cursor = s - 1;
-        if (int rc = adjoint_march_step<T>(p, (T*)p->adjE_alt, (T*)p->adjH_alt, (T*)lamE, (T*)lamH, 2))
+        if (int rc = adjoint_march_step<T>(p, (T*)p->adjE_alt, (T*)p->adjH_alt, (T*)lamE, (T*)lamH, (T*)work, 2))
           return rc;
       }
       p->trace_cursor = -1;

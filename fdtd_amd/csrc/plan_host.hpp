@@ -194,10 +194,6 @@ struct fdtdhip_plan {
   int32_t* detmap = nullptr;
   int detmap_state = 0;
   void *adjE_alt = nullptr, *adjH_alt = nullptr;   // second adjoint fields of whole reverse steps
-  // whole reverse steps: the launches over the box around the objects run beside those over
-  // the PML slabs, on a stream of the plan's own (created on first use)
-  hipStream_t side = nullptr;
-  hipEvent_t side_fork = nullptr, side_join = nullptr;
   void* adj_work = nullptr;   // second `work` array of the paired adjoint launches (owned)
   int64_t adj_work_bytes = 0;
   int64_t trace_cursor = -1;  // row of the curl traces the next E half step writes; -1: no traces

@@ -307,6 +307,29 @@ __global__ __launch_bounds__(256) void adj_shell_E(AdjArgs<T> a, const T* __rest
   lamG_out[c3 + 2] = o[2] + add[2];
 }
 
+// Pass 2 over boxes of cells, out of place: adj_gather's sums with lamG_out = lamG_in + ...
+// For the box around the objects, whose cells keep the two passes in the E half step (pass 1,
+// adj_E_cells, is one evaluation per cell where adj_shell_E makes four, each a chain of
+// dependent loads through the object table: 35 us against 12 + 8 us for a 66^3 box) and are
+// all plain in the H half step (objects do not act there: no pass 1, the direct form).
+template <typename T, bool PHASE_E>
+__global__ __launch_bounds__(256) void adj_shell_gather(AdjArgs<T> a, const T* __restrict__ lamG_in,
+                                                        T* __restrict__ lamG_out, CellBoxes box) {
+  int i, j, k;
+  if (!box_lane_cell(box, i, j, k)) return;
+  const int64_t c3 = (((int64_t)i * a.ny + j) * a.nz + k) * 3;
+  const T o[3] = {lamG_in[c3], lamG_in[c3 + 1], lamG_in[c3 + 2]};
+  T add[3];
+  if (a.direct && (PHASE_E ? adj_box_plain(a, i, i + 1, j, j + 1, k, k + 1)
+                           : adj_box_plain(a, i - 1, i, j - 1, j, k - 1, k)))
+    adj_gather_direct<T, PHASE_E>(a, i, j, k, add);
+  else
+    adj_gather_cell<T, PHASE_E>(a, i, j, k, add);
+  lamG_out[c3] = o[0] + add[0];
+  lamG_out[c3 + 1] = o[1] + add[1];
+  lamG_out[c3 + 2] = o[2] + add[2];
+}
+
 // ---- the same for PML slabs without objects, every load requested up front ---------------
 // adj_shell_H / adj_shell_E walk the plan's PML table cell by cell, four times per lane: chains
 // of dependent round trips (descriptor, memory variables, profiles) that leave the memory
