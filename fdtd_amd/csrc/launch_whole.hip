@@ -79,7 +79,6 @@ FusedKind fused_kind(const fdtdhip_plan* p, bool staged) {
     if (o.kind == FDTDHIP_OBJ_ANISOTROPIC_MODULATED) return FUSED_NONE;  // only the generic E kernel has them
   const bool halo = p->H_below || p->E_above;
   if (halo && !staged) return FUSED_NONE;
-  if (staged && p->trace_cursor >= 0) return FUSED_NONE;   // recorded runs on slabs: half steps
   for (const DetH& d : p->dets)
     if (staged && d.below) return FUSED_NONE;   // read between the post pieces and a plane exchange
   for (const BoundaryRef& b : p->boundaries)

@@ -96,8 +96,8 @@ struct AdjArgs {
   // x-slabs: the slab continues below plane 0 / above plane nx-1 on a neighbour rank, so the
   // x differences at that face exist (they read the neighbour's plane in the forward pass)
   int open_lo, open_hi;
-  const T* wghost;     // pass 2: the neighbour's `work` plane across the face the gather
-                       // reaches over ((ny,nz,6)), or null
+  const T* wghost;     // pass 2: across the face the gather reaches over, the two difference
+                       // adjoints along x (WX_Y, WX_Z) of the neighbour's plane, (ny,nz,2); or null
   int mat_const;       // as in BulkArgs: `mat` is bg outside the object boxes, zero inside
   T bg[3];
   int hull[6];         // box containing every object

@@ -469,7 +469,7 @@ __device__ __forceinline__ void adj_gather_cell(const AdjArgs<T>& a, int i, int 
   // x neighbour: inside the slab, or the neighbour rank's plane, or nothing at a domain edge
   auto nbx = [&](bool inside, int64_t off, bool open, int which) {
     if (inside) return w[off + which];
-    return open && a.wghost ? a.wghost[r * 6 + which] : T(0);
+    return open && a.wghost ? a.wghost[r * 2 + which] : T(0);   // (WX_Y, WX_Z are entries 0 and 1)
   };
   if (PHASE_E) {
     const bool ox = i < a.nx - 1, oy = j < a.ny - 1, oz = k < a.nz - 1;

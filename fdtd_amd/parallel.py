@@ -323,6 +323,9 @@ class SlabGrid(Grid):
         self._native_run(None, n)
         self.time_steps_passed += n
 
+    def _provide_step_buffers(self, slab=True):
+        super()._provide_step_buffers(slab=True)
+
     def _any_rank_needs_grad(self):
         """Whether this run has to be recorded for a backward pass.  Collective when gradients
         are enabled: the reverse sweep exchanges planes between neighbours, so either every
@@ -384,9 +387,9 @@ class SlabGrid(Grid):
         eng.prepare(n)
         eng.reserve_detectors(n, n)
         s = 0
-        # (lib is None: called by _advance for a run that is not recorded; the forward pass of
-        # a recorded run keeps to half steps, whose curl traces its reverse sweep reads)
-        if lib is None and self._whole_steps_agreed(eng, n):
+        # (recorded runs too: the E half step of the box around the objects, which the shell
+        # launches take, writes the curl traces the reverse sweep reads)
+        if self._whole_steps_agreed(eng, n):
             # pairs of whole steps, first -> second buffers and back: the state ends in the
             # tensors the user holds; an odd last step runs as two half steps
             cur = (self.E.detach(), self.H.detach())
@@ -409,13 +412,21 @@ class SlabGrid(Grid):
         neighbour's plane, so their adjoints flow back across it: undoing the H half step,
         plane 0 gathers from the LAST plane of difference adjoints of the rank below;
         undoing the E half step, the last plane gathers from the FIRST plane of the rank
-        above.  One ``(Ny, Nz, 6)`` plane per half step and neighbour, as in the forward
+        above.  One packed ``(Ny, Nz, 2)`` plane per half step and neighbour, as in the forward
         pass."""
         r, p, plan = self._rank, self._world, self._plan
         ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
         planes = work.view(self.Nx, self.Ny, self.Nz, 6)
-        from_below = bd.zeros((self.Ny, self.Nz, 6)) if r > 0 else None
-        from_above = bd.zeros((self.Ny, self.Nz, 6)) if r < p - 1 else None
+        # what crosses a face: the adjoints of the two differences along x, entries 0 and 1 of a
+        # cell's six -- a packed (Ny, Nz, 2) plane, the size of the forward halo
+        from_below = bd.zeros((self.Ny, self.Nz, 2)) if r > 0 else None
+        from_above = bd.zeros((self.Ny, self.Nz, 2)) if r < p - 1 else None
+        send = bd.zeros((self.Ny, self.Nz, 2)) if p > 1 else None
+
+        def across(plane):
+            send.copy_(plane[..., :2])
+            return send
+
         wrap = self._x_wrap
         wrapped = bd.zeros((self.Ny, self.Nz, 3)) if wrap and r in (0, p - 1) else None
 
@@ -443,7 +454,7 @@ class SlabGrid(Grid):
             if wrap:
                 undo_wrap(0, s, lamH)
             _lib.check(lib.fdtdhip_adjoint_cells(plan, 0, s, ptr(lamE), ptr(lamH), ptr(work)))
-            ex = self._start_exchange(planes[-1] if r < p - 1 else None, r + 1, from_below, r - 1)
+            ex = self._start_exchange(across(planes[-1]) if r < p - 1 else None, r + 1, from_below, r - 1)
             if ex is not None:
                 ex.wait()
             _lib.check(lib.fdtdhip_adjoint_gather(plan, 0, ptr(lamE), ptr(lamH), ptr(work),
@@ -453,7 +464,7 @@ class SlabGrid(Grid):
             if wrap:
                 undo_wrap(1, s, lamE)
             _lib.check(lib.fdtdhip_adjoint_cells(plan, 1, s, ptr(lamE), ptr(lamH), ptr(work)))
-            ex = self._start_exchange(planes[0] if r > 0 else None, r - 1, from_above, r + 1)
+            ex = self._start_exchange(across(planes[0]) if r > 0 else None, r - 1, from_above, r + 1)
             if ex is not None:
                 ex.wait()
             _lib.check(lib.fdtdhip_adjoint_gather(plan, 1, ptr(lamE), ptr(lamH), ptr(work),

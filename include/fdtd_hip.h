@@ -365,11 +365,14 @@ int fdtdhip_adjoint_run_noalloc(fdtdhip_plan* plan, int64_t nsteps, void* lamE, 
  *   fdtdhip_adjoint_gather : transpose of the difference stencil, added to the adjoint of
  *                            the driving field.  The differences across an x face between
  *                            slabs (reference fdtd/grid.py:46,48,71,73) make the gather reach
- *                            into the neighbour's `work`: for the E half step (phase_E = 1)
- *                            `work_ghost` is the FIRST work plane of the rank above, for the
- *                            H half step the LAST work plane of the rank below, each a
- *                            contiguous (ny, nz, 6) block exchanged by the caller between
- *                            the two calls; NULL where the slab ends at a domain edge.
+ *                            into the neighbour's `work`.  Only the adjoints of the two
+ *                            differences along x cross the face -- entries 0 and 1 of the six
+ *                            of a cell -- so `work_ghost` is a packed (ny, nz, 2) array: for
+ *                            the E half step (phase_E = 1) work[plane 0][..., 0:2] of the rank
+ *                            above, for the H half step work[last plane][..., 0:2] of the
+ *                            rank below, exchanged by the caller between the two calls (the
+ *                            size of the forward halo); NULL where the slab ends at a domain
+ *                            edge.
  * A reverse step undoes the H half step first (phase_E = 0), then the E half step.
  * With FDTDHIP_PERIODIC_X_EXTERNAL in the plan (the copy between the first and the last rank
  * is the caller's, reference fdtd/boundaries.py:173-184) fdtdhip_adjoint_cells leaves the
