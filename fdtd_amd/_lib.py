@@ -68,6 +68,9 @@ PROTOTYPES = {
     "fdtdhip_plan_set_pml_adjoint": (_i, [_p, _i, _p, _p]),
     "fdtdhip_plan_set_adjoint_buffers": (_i, [_p, _p, _p]),
     "fdtdhip_plan_set_pml_adjoint_buffers": (_i, [_p, _i, _p, _p]),
+    "fdtdhip_plan_adjoint_whole_steps": (_i, [_p]),
+    "fdtdhip_adjoint_pack_plane": (_i, [_p, _i, _i64, _i, _p, _p, _p]),
+    "fdtdhip_adjoint_step_stage": (_i, [_p, _i64, _i, _i, _p, _p, _p, _p, _p, _p]),
     "fdtdhip_adjoint_run": (_i, [_p, _i64, _p, _p, _p]),
     "fdtdhip_adjoint_run_noalloc": (_i, [_p, _i64, _p, _p]),
     "fdtdhip_adjoint_cells": (_i, [_p, _i, _i64, _p, _p, _p]),

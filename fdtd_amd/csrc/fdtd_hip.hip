@@ -575,6 +575,33 @@ int fdtdhip_adjoint_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH,
   return adj_run(p, nsteps, lamE, lamH, work);
 }
 
+int fdtdhip_plan_adjoint_whole_steps(fdtdhip_plan* p) {
+  if (!p) return fail(-1, "null plan");
+  GUARD(p);
+  return adj_stage_possible(p);
+}
+
+int fdtdhip_adjoint_pack_plane(fdtdhip_plan* p, int phase_E, int64_t step, int flip, void* lamE, void* lamH,
+                               void* out) {
+  if (!p) return fail(-1, "null plan");
+  GUARD(p);
+  p->trace_cursor = step;
+  const int rc = adj_pack(p, phase_E != 0, lamE, lamH, out, flip);
+  p->trace_cursor = -1;
+  return rc;
+}
+
+int fdtdhip_adjoint_step_stage(fdtdhip_plan* p, int64_t step, int stage, int flip, void* lamE0, void* lamH0,
+                               void* lamE1, void* lamH1, void* work, const void* ghost) {
+  if (!p) return fail(-1, "null plan");
+  if (stage < 0 || stage > 3) return fail(-1, "stage is 0..3");
+  GUARD(p);
+  p->trace_cursor = step;
+  const int rc = adj_stage(p, stage, lamE0, lamH0, lamE1, lamH1, work, flip, ghost);
+  p->trace_cursor = -1;
+  return rc;
+}
+
 int fdtdhip_adjoint_run_noalloc(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH) {
   if (!p) return fail(-1, "null plan");
   if (!lamE || !lamH) return fail(-1, "null adjoint array");

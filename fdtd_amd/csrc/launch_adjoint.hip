@@ -103,9 +103,11 @@ int cell_box_table(const std::vector<CellBox>& boxes, CellBoxes& tab) {
 // axis), and the hull of the objects grown by one cell where it lies in that part (`hole`,
 // all zero without objects).  The boxes are disjoint: pass 1 has side effects
 // (memory-variable adjoints, object gradients).
+// boxes: [0] the slab below [s0, s1) along x, [1] the slab above it, [2..5] the y and z slabs
+// between them, [6] (with objects) the box around the objects; empty ones included.
 template <typename T>
-int adjoint_shell_boxes(const fdtdhip_plan* p, const AdjArgs<T>& a, CellBoxes& tab, int (&s0)[3],
-                        int (&s1)[3], int (&hole)[6]) {
+void adjoint_shell_box_list(const fdtdhip_plan* p, const AdjArgs<T>& a, std::vector<CellBox>& boxes,
+                            int (&s0)[3], int (&s1)[3], int (&hole)[6]) {
   const int n[3] = {p->nx, p->ny, p->nz};
   for (int d = 0; d < 3; ++d) {
     s0[d] = a.core[2 * d] + (a.core[2 * d] > 0 ? 1 : 0);
@@ -115,7 +117,7 @@ int adjoint_shell_boxes(const fdtdhip_plan* p, const AdjArgs<T>& a, CellBoxes& t
     s0[d] = std::min(std::max(s0[d], 0), n[d]);
     s1[d] = std::min(std::max(s1[d], s0[d]), n[d]);
   }
-  std::vector<CellBox> boxes = {
+  boxes = {
       {0, s0[0], 0, n[1], 0, n[2]},           {s1[0], n[0], 0, n[1], 0, n[2]},
       {s0[0], s1[0], 0, s0[1], 0, n[2]},      {s0[0], s1[0], s1[1], n[1], 0, n[2]},
       {s0[0], s1[0], s0[1], s1[1], 0, s0[2]}, {s0[0], s1[0], s0[1], s1[1], s1[2], n[2]}};
@@ -129,6 +131,13 @@ int adjoint_shell_boxes(const fdtdhip_plan* p, const AdjArgs<T>& a, CellBoxes& t
       hole[0] = h.i0; hole[1] = h.i1; hole[2] = h.j0; hole[3] = h.j1; hole[4] = h.k0; hole[5] = h.k1;
     }
   }
+}
+
+template <typename T>
+int adjoint_shell_boxes(const fdtdhip_plan* p, const AdjArgs<T>& a, CellBoxes& tab, int (&s0)[3],
+                        int (&s1)[3], int (&hole)[6]) {
+  std::vector<CellBox> boxes;
+  adjoint_shell_box_list<T>(p, a, boxes, s0, s1, hole);
   return cell_box_table(boxes, tab);
 }
 
@@ -296,13 +305,16 @@ int adjoint_march_mode() {
 // adjoints between the half steps (no recorded periodic boundary and hence no PML whose
 // correction follows one; only additive point sources, which have no adjoint of their own),
 // a box of plain cells to march over.
+// `staged`: asked for fdtdhip_adjoint_step_stage, the whole reverse step in pieces around the
+// plane exchanges of an x-slab (open faces allowed).
 template <typename T>
-bool adjoint_march_eligible(fdtdhip_plan* p, const AdjArgs<T>& a, const int (&s0)[3], const int (&s1)[3]) {
+bool adjoint_march_eligible(fdtdhip_plan* p, const AdjArgs<T>& a, const int (&s0)[3], const int (&s1)[3],
+                            bool staged = false) {
   const int mode = adjoint_march_mode();
-  if (mode == 0 || !p->adjE_alt || !p->adjH_alt || !a.direct) return false;
+  if (mode == 0 || !p->adjE_alt || !p->adjH_alt || !a.direct || p->no_alloc) return false;
   for (const PmlH& h : p->pmls)
     if (!h.lamE_alt || !h.lamH_alt) return false;
-  if (p->H_below || p->E_above) return false;
+  if ((p->H_below || p->E_above) && !staged) return false;
   for (const BoundaryRef& b : p->boundaries)
     if (b.kind == 1) return false;
   for (const SourceH& s : p->sources)
@@ -319,7 +331,7 @@ bool adjoint_march_eligible(fdtdhip_plan* p, const AdjArgs<T>& a, const int (&s0
 template <typename T, int TY, int MW>
 int launch_adjoint_march_tiles(fdtdhip_plan* p, const AdjArgs<T>& e, const AdjArgs<T>& h, const T* lamE0,
                                const T* lamH0, T* lamE1, T* lamH1, const int (&s0)[3],
-                               const int (&s1)[3], const int (&hole)[6]) {
+                               const int (&s1)[3], const int (&hole)[6], int part) {
   AdjMarchArgs<T> m;
   m.lamE0 = lamE0; m.lamH0 = lamH0; m.lamE1 = lamE1; m.lamH1 = lamH1;
   m.nx = p->nx; m.ny = p->ny; m.nz = p->nz;
@@ -332,22 +344,22 @@ int launch_adjoint_march_tiles(fdtdhip_plan* p, const AdjArgs<T>& e, const AdjAr
   const int tiles = (s1[1] - s0[1] + TY - 1) / TY, planes = s1[0] - s0[0];
   const int waves = (p->nz + 63) / 64;
   void (*kernel)(AdjMarchArgs<T>) = holed ? adj_march_box<T, TY, true, MW> : adj_march_box<T, TY, false, MW>;
-  const int lx = m.lx = march_chunk_planes(planes, tiles, march_slots(p, (const void*)kernel, 64 * waves));
+  // part: 0 all chunks of planes in one launch, 1 / 2 the first / second half of them (each
+  // half should fill its rounds of workgroups)
+  const int lx = m.lx = march_chunk_planes(part == 0 ? planes : (planes + 1) / 2, tiles,
+                                           march_slots(p, (const void*)kernel, 64 * waves));
+  const int nchunks = (planes + lx - 1) / lx, half = nchunks / 2;
   m.band = tiles >= 16 ? (tiles + 7) / 8 : 0;
-  m.chunk0 = 0;
-  const dim3 grid(m.band ? 8 * m.band : tiles, (planes + lx - 1) / lx, 1), block(64 * waves);
-  hipLaunchKernelGGL(kernel, grid, block, 0, p->stream, m);
-  HIPCHK(hipGetLastError());
+  m.chunk0 = part == 2 ? half : 0;
+  const int count = part == 0 ? nchunks : (part == 1 ? half : nchunks - half);
+  if (count > 0) {
+    const dim3 grid(m.band ? 8 * m.band : tiles, count, 1), block(64 * waves);
+    hipLaunchKernelGGL(kernel, grid, block, 0, p->stream, m);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }
 
-// One whole reverse step, out of place: (lamE0, lamH0) after the step -> (lamE1, lamH1)
-// before it; memory-variable adjoints from one set of arrays to the other (`flip`: 1 first ->
-// second, 2 back).
-//   adj_shell_H over the cells next to PML slabs and objects     lamE1 = lamE0 + ...
-//   adj_march_box over the plain cells                            lamE1, lamH1 of the box
-//   adj_shell_E over the cells next to PML slabs and objects     lamH1 = lamH0 + ...
-//   adj_rescale_absorbing over the box of the objects             lamE1 under absorbing objects
 // The PML faces of a plan as arguments of adj_shell_faces, if the plan qualifies: at most one
 // face per side of an axis, the two faces of an axis apart, and no object next to a slab (so
 // that every cell those launches evaluate has the constant material).
@@ -381,24 +393,37 @@ bool adjoint_face_set(const fdtdhip_plan* p, bool phaseE, int flip, const AdjArg
 
 // One whole reverse step, out of place: (lamE0, lamH0) after the step -> (lamE1, lamH1)
 // before it; memory-variable adjoints from one set of arrays to the other (`flip`: 1 first ->
-// second, 2 back).
-//   H half step undone in the cells next to PML slabs and objects     lamE1 = lamE0 + ...
-//   adj_march_box over the plain cells                                 lamE1, lamH1 of the box
-//   E half step undone in the cells next to PML slabs and objects     lamH1 = lamH0 + ...
+// second, 2 back).  In pieces (`stages`, a mask of AST_*), so that an x-slab can place them
+// around its two plane exchanges -- the mirror image of the forward step in stages:
+//   AST_H_FREE   H half step undone in the cells next to PML slabs, objects and the high face
+//                of the slab (all but plane 0 of a slab that continues below)
+//   AST_MARCH_A  adj_march_box over the first half of the planes of the plain cells
+//   AST_H_GHOST  H half step undone in plane 0, which gathers from the plane of the rank below
+//   AST_MARCH_B  the second half of the planes
+//   AST_E_FREE   E half step undone in the cells next to PML slabs, objects and the low face
+//                (all but the last plane of a slab that continues above)
+//   AST_E_GHOST  E half step undone in the last plane, which gathers from the rank above
+// The marching kernel reads the new lamE of plane 0 nowhere (its lowest plane is plane 1,
+// which gathers from plane 2), so every operand is the one the two-pass sweep would use.
 // Where the plan qualifies (adjoint_face_set) the slabs take adj_shell_faces and the box around
 // the objects the two passes through `work` (adj_E_cells, adj_shell_gather);
 // otherwise all of them take the table-walking adj_shell_H / adj_shell_E and
-// adj_rescale_absorbing rescales lamE1 under absorbing objects afterwards.
+// adj_rescale_absorbing rescales lamE1 under absorbing objects at the end.
+enum { AST_H_FREE = 1, AST_MARCH_A = 2, AST_H_GHOST = 4, AST_MARCH_B = 8, AST_E_FREE = 16, AST_E_GHOST = 32,
+       AST_ALL = 63 };
+
 template <typename T>
-int adjoint_march_step(fdtdhip_plan* p, T* lamE0, T* lamH0, T* lamE1, T* lamH1, T* work, int flip) {
+int adjoint_march_pieces(fdtdhip_plan* p, T* lamE0, T* lamH0, T* lamE1, T* lamH1, T* work, int flip,
+                         int stages, const T* ghost) {
   AdjArgs<T> h, e;
-  CellBoxes tab;
+  std::vector<CellBox> boxes;
   int s0[3], s1[3], hole[6];
   // (the boxes of the E half step: objects act in that half step only, but every cell the
   // marching kernel leaves out needs both half steps undone here)
-  if (int rc = adjoint_args<T>(p, true, lamE1, lamH0, (T*)nullptr, e, flip)) return rc;
-  if (int rc = adjoint_shell_boxes<T>(p, e, tab, s0, s1, hole)) return rc;
-  if (int rc = adjoint_args<T>(p, false, lamE0, lamH0, (T*)nullptr, h, flip)) return rc;
+  if (int rc = adjoint_args<T>(p, true, lamE1, lamH0, work, e, flip)) return rc;
+  adjoint_shell_box_list<T>(p, e, boxes, s0, s1, hole);
+  if (int rc = adjoint_args<T>(p, false, lamE0, lamH0, work, h, flip)) return rc;
+  e.wghost = h.wghost = ghost;
   static const bool faces_off = [] {
     const char* v = getenv("FDTDHIP_ADJ_FACES");
     return v && atoi(v) == 0;
@@ -406,67 +431,129 @@ int adjoint_march_step(fdtdhip_plan* p, T* lamE0, T* lamH0, T* lamE1, T* lamH1, 
   AdjFaceSet<T> fe, fh;
   const bool faces = !faces_off && adjoint_face_set<T>(p, true, flip, e, s0, s1, fe) &&
                      adjoint_face_set<T>(p, false, flip, e, s0, s1, fh);
-  CellBoxes slabs = tab, rest = tab;
-  if (faces) {
-    // the slabs are the first boxes of the table, the box around the objects its last
-    std::vector<CellBox> a, b;
-    const bool holed = hole[1] > hole[0];
-    for (int n = 0; n < tab.count; ++n) (holed && n == tab.count - 1 ? b : a).push_back(tab.box[n]);
-    if (int rc = cell_box_table(a, slabs)) return rc;
-    if (int rc = cell_box_table(b, rest)) return rc;
-  }
   const dim3 block(256);
   bool absorbing = false;
   for (const ObjH& o : p->objs) absorbing |= o.kind == FDTDHIP_OBJ_ABSORBING;
   const int64_t hull = (int64_t)std::max(e.hull[1] - e.hull[0], 0) * std::max(e.hull[3] - e.hull[2], 0) *
                        std::max(e.hull[5] - e.hull[4], 0);
-  auto shell = [&](bool phaseE) -> int {
+  // one half step undone over the boxes `which` (indices into `boxes`)
+  auto shell = [&](bool phaseE, std::initializer_list<int> which) -> int {
     const AdjArgs<T>& a = phaseE ? e : h;
     const T* in = phaseE ? lamH0 : lamE0;
     T* out = phaseE ? lamH1 : lamE1;
-    // (the launches over the box around the objects on a second stream, beside those over
-    // the slabs, were measured: both slowed down, 0.36 against 0.33 ms per reverse step at
-    // 256^3 with a 64^3 box, no difference at 512^3)
-    hipStream_t rest_stream = p->stream;
-    if (faces && slabs.count) {
+    std::vector<CellBox> sl, ob;
+    for (int n : which)
+      if (n < (int)boxes.size()) (faces && n == 6 ? ob : sl).push_back(boxes[n]);
+    CellBoxes slabs, rest;
+    if (int rc = cell_box_table(sl, slabs)) return rc;
+    if (int rc = cell_box_table(ob, rest)) return rc;
+    if (slabs.count) {
       const dim3 grid((unsigned)slabs.first[slabs.count]);
-      if (phaseE) hipLaunchKernelGGL((adj_shell_faces<T, true>), grid, block, 0, p->stream, a, fe, in, out, slabs);
-      else hipLaunchKernelGGL((adj_shell_faces<T, false>), grid, block, 0, p->stream, a, fh, in, out, slabs);
-    }
-    if (rest.count && faces) {
-      // the box around the objects alone (no PML slab near it): two passes in the E half step,
-      // none but the gather in the H half step, where all of its cells are plain
-      const dim3 grid((unsigned)rest.first[rest.count]);
-      AdjArgs<T> w = a;
-      w.work = work;
-      if (phaseE) {
-        hipLaunchKernelGGL((adj_E_cells<T, true, true>), grid, block, 0, rest_stream, w, rest);
-        hipLaunchKernelGGL((adj_shell_gather<T, true>), grid, block, 0, rest_stream, w, in, out, rest);
+      if (faces) {
+        if (phaseE) hipLaunchKernelGGL((adj_shell_faces<T, true>), grid, block, 0, p->stream, a, fe, in, out, slabs);
+        else hipLaunchKernelGGL((adj_shell_faces<T, false>), grid, block, 0, p->stream, a, fh, in, out, slabs);
       } else {
-        hipLaunchKernelGGL((adj_shell_gather<T, false>), grid, block, 0, rest_stream, w, in, out, rest);
+        if (phaseE) hipLaunchKernelGGL((adj_shell_E<T>), grid, block, 0, p->stream, a, in, out, slabs);
+        else hipLaunchKernelGGL((adj_shell_H<T>), grid, block, 0, p->stream, a, in, out, slabs);
       }
-    } else if (rest.count) {
+    }
+    if (rest.count) {
+      // the box around the objects alone (no PML slab near it): two passes in the E half step,
+      // none but the gather in the H half step, where all of its cells are plain.  (On a
+      // second stream beside the slab launches both slowed down: 0.36 against 0.33 ms per
+      // reverse step at 256^3 with a 64^3 box.)
       const dim3 grid((unsigned)rest.first[rest.count]);
-      if (phaseE) hipLaunchKernelGGL((adj_shell_E<T>), grid, block, 0, rest_stream, a, in, out, rest);
-      else hipLaunchKernelGGL((adj_shell_H<T>), grid, block, 0, rest_stream, a, in, out, rest);
-      // (lamE1 under absorbing objects: once every lane of adj_shell_E has read it)
-      if (phaseE && absorbing && hull > 0)
-        hipLaunchKernelGGL((adj_rescale_absorbing<T>), dim3(blocks_for(hull)), block, 0, rest_stream, e, lamE1);
+      if (phaseE) {
+        hipLaunchKernelGGL((adj_E_cells<T, true, true>), grid, block, 0, p->stream, a, rest);
+        hipLaunchKernelGGL((adj_shell_gather<T, true>), grid, block, 0, p->stream, a, in, out, rest);
+      } else {
+        hipLaunchKernelGGL((adj_shell_gather<T, false>), grid, block, 0, p->stream, a, in, out, rest);
+      }
     }
     HIPCHK(hipGetLastError());
     return 0;
   };
-  if (int rc = shell(false)) return rc;
-  if ((p->nz + 63) / 64 <= 8) {
-    if (int rc = launch_adjoint_march_tiles<T, sizeof(T) == 4 ? FDTDHIP_ADJ_MARCH_TY32 : FDTDHIP_ADJ_MARCH_TY64, 8>(
-            p, e, h, lamE0, lamH0, lamE1, lamH1, s0, s1, hole))
-      return rc;
-  } else {
-    if (int rc = launch_adjoint_march_tiles<T, sizeof(T) == 4 ? FDTDHIP_ADJ_MARCH_TY32 : 2, ADJ_MARCH_MAX_WAVES>(
-            p, e, h, lamE0, lamH0, lamE1, lamH1, s0, s1, hole))
-      return rc;
+  auto march = [&](int part) -> int {
+    if ((p->nz + 63) / 64 <= 8)
+      return launch_adjoint_march_tiles<T, sizeof(T) == 4 ? FDTDHIP_ADJ_MARCH_TY32 : FDTDHIP_ADJ_MARCH_TY64, 8>(
+          p, e, h, lamE0, lamH0, lamE1, lamH1, s0, s1, hole, part);
+    return launch_adjoint_march_tiles<T, sizeof(T) == 4 ? FDTDHIP_ADJ_MARCH_TY32 : 2, ADJ_MARCH_MAX_WAVES>(
+        p, e, h, lamE0, lamH0, lamE1, lamH1, s0, s1, hole, part);
+  };
+  const bool lo = e.open_lo, hi = e.open_hi;   // plane 0 / the last plane wait for a neighbour's plane
+  if (stages & AST_H_FREE) {
+    if (lo) { if (int rc = shell(false, {1, 2, 3, 4, 5, 6})) return rc; }
+    else if (int rc = shell(false, {0, 1, 2, 3, 4, 5, 6})) return rc;
   }
-  return shell(true);
+  const bool both = (stages & AST_MARCH_A) && (stages & AST_MARCH_B);
+  if (both) { if (int rc = march(0)) return rc; }
+  else if (stages & AST_MARCH_A) { if (int rc = march(1)) return rc; }
+  if ((stages & AST_H_GHOST) && lo)
+    if (int rc = shell(false, {0})) return rc;
+  if (!both && (stages & AST_MARCH_B))
+    if (int rc = march(2)) return rc;
+  if (stages & AST_E_FREE) {
+    if (hi) { if (int rc = shell(true, {0, 2, 3, 4, 5, 6})) return rc; }
+    else if (int rc = shell(true, {0, 1, 2, 3, 4, 5, 6})) return rc;
+  }
+  if (stages & AST_E_GHOST) {
+    if (hi)
+      if (int rc = shell(true, {1})) return rc;
+    // (lamE1 under absorbing objects: once every lane of adj_shell_E has read it; the two
+    // passes of the other form rescale it in their pass 1)
+    if (!faces && absorbing && hull > 0)
+      hipLaunchKernelGGL((adj_rescale_absorbing<T>), dim3(blocks_for(hull)), block, 0, p->stream, e, lamE1);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int adjoint_march_step(fdtdhip_plan* p, T* lamE0, T* lamH0, T* lamE1, T* lamH1, T* work, int flip) {
+  return adjoint_march_pieces<T>(p, lamE0, lamH0, lamE1, lamH1, work, flip, AST_ALL, (const T*)nullptr);
+}
+
+// Whether fdtdhip_adjoint_step_stage can walk this plan (second arrays set, see adjoint_march_eligible).
+template <typename T>
+int adjoint_stage_possible(fdtdhip_plan* p) {
+  if (!p->inv_eps || !p->inv_mu) return 0;
+  AdjArgs<T> a;
+  std::vector<CellBox> boxes;
+  int s0[3], s1[3], hole[6];
+  if (sync_obj_table<T>(p)) return 0;
+  for (const PmlH& h : p->pmls)
+    if (!h.lamE || !h.lamH) return 0;
+  if (adjoint_args<T>(p, true, (T*)nullptr, (T*)nullptr, (T*)nullptr, a)) return 0;
+  adjoint_shell_box_list<T>(p, a, boxes, s0, s1, hole);
+  return adjoint_march_eligible<T>(p, a, s0, s1, true) ? 1 : 0;
+}
+
+// One piece of a whole reverse step on an x-slab (fdtdhip_adjoint_step_stage).
+template <typename T>
+int adjoint_stage(fdtdhip_plan* p, int stage, T* lamE0, T* lamH0, T* lamE1, T* lamH1, T* work, int flip,
+                  const T* ghost) {
+  if (!lamE0 || !lamH0 || !lamE1 || !lamH1 || !work) return fail(-1, "null adjoint array");
+  if (flip != 1 && flip != 2) return fail(-1, "flip is 1 (first -> second arrays) or 2 (back)");
+  if (int rc = sync_obj_table<T>(p)) return rc;
+  if (stage == 0 && !adjoint_stage_possible<T>(p))
+    return fail(-1, "this plan cannot take whole reverse steps in stages (fdtdhip_plan_adjoint_whole_steps)");
+  static const int pieces[4] = {AST_H_FREE | AST_MARCH_A, AST_H_GHOST, AST_MARCH_B | AST_E_FREE, AST_E_GHOST};
+  return adjoint_march_pieces<T>(p, lamE0, lamH0, lamE1, lamH1, work, flip, pieces[stage], ghost);
+}
+
+// The plane a rank sends across an open face in a whole reverse step (adj_pack_plane).
+template <typename T>
+int adjoint_pack(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* out, int flip) {
+  if (!lamE || !lamH || !out) return fail(-1, "null adjoint array");
+  if (int rc = sync_obj_table<T>(p)) return rc;
+  AdjArgs<T> a;
+  if (int rc = adjoint_args<T>(p, phaseE, lamE, lamH, (T*)nullptr, a, flip)) return rc;
+  const int64_t plane = (int64_t)p->ny * p->nz;
+  const int i = phaseE ? 0 : p->nx - 1;
+  if (phaseE) hipLaunchKernelGGL((adj_pack_plane<T, true>), dim3(blocks_for(plane)), dim3(256), 0, p->stream, a, i, out);
+  else hipLaunchKernelGGL((adj_pack_plane<T, false>), dim3(blocks_for(plane)), dim3(256), 0, p->stream, a, i, out);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 // The paired adjoint launches serve plans in which nothing acts on the field adjoints
@@ -698,6 +785,23 @@ int adj_cells(fdtdhip_plan* p, bool phaseE, void* lamE, void* lamH, void* work) 
 int adj_gather(fdtdhip_plan* p, bool phaseE, void* lamE, void* lamH, void* work, const void* wghost) {
   return DISPATCH(p, adjoint_gather<float>(p, phaseE, (float*)lamE, (float*)lamH, (float*)work, (const float*)wghost),
                   adjoint_gather<double>(p, phaseE, (double*)lamE, (double*)lamH, (double*)work, (const double*)wghost));
+}
+
+int adj_stage_possible(fdtdhip_plan* p) {
+  return DISPATCH(p, adjoint_stage_possible<float>(p), adjoint_stage_possible<double>(p));
+}
+
+int adj_stage(fdtdhip_plan* p, int stage, void* lamE0, void* lamH0, void* lamE1, void* lamH1, void* work,
+              int flip, const void* ghost) {
+  return DISPATCH(p, adjoint_stage<float>(p, stage, (float*)lamE0, (float*)lamH0, (float*)lamE1, (float*)lamH1,
+                                          (float*)work, flip, (const float*)ghost),
+                  adjoint_stage<double>(p, stage, (double*)lamE0, (double*)lamH0, (double*)lamE1, (double*)lamH1,
+                                        (double*)work, flip, (const double*)ghost));
+}
+
+int adj_pack(fdtdhip_plan* p, bool phaseE, void* lamE, void* lamH, void* out, int flip) {
+  return DISPATCH(p, adjoint_pack<float>(p, phaseE, (float*)lamE, (float*)lamH, (float*)out, flip),
+                  adjoint_pack<double>(p, phaseE, (double*)lamE, (double*)lamH, (double*)out, flip));
 }
 
 int adj_post(fdtdhip_plan* p, bool phaseE, void* lamE, void* lamH, int stage) {

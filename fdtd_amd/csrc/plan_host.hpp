@@ -449,5 +449,9 @@ int adj_run_noalloc(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH);
 int adj_cells(fdtdhip_plan* p, bool phaseE, void* lamE, void* lamH, void* work);
 int adj_gather(fdtdhip_plan* p, bool phaseE, void* lamE, void* lamH, void* work, const void* wghost);
 int adj_post(fdtdhip_plan* p, bool phaseE, void* lamE, void* lamH, int stage);
+int adj_stage_possible(fdtdhip_plan* p);
+int adj_stage(fdtdhip_plan* p, int stage, void* lamE0, void* lamH0, void* lamE1, void* lamH1, void* work,
+              int flip, const void* ghost);
+int adj_pack(fdtdhip_plan* p, bool phaseE, void* lamE, void* lamH, void* out, int flip);
 
 }  // namespace fdtdhip

@@ -266,10 +266,14 @@ __global__ __launch_bounds__(256) void adj_shell_H(AdjArgs<T> a, const T* __rest
   adj_H_cell<T, 1>(a, i, oy ? j - 1 : j, k, oy ? c3 - sy : c3, vy, wy, false);
   adj_H_cell<T, 2>(a, i, j, oz ? k - 1 : k, oz ? c3 - 3 : c3, vz, wz, false);
   const T zero = T(0);
+  // plane 0 of an x-slab: the two entries of the cell below come from the rank below
+  const bool ghost = !ox && a.open_lo && a.wghost;
+  const int64_t gr = ((int64_t)j * a.nz + k) * 2;
+  const T bxy = ghost ? a.wghost[gr] : zero, bxz = ghost ? a.wghost[gr + 1] : zero;
   T add[3];
   add[0] = ((oy ? wy[WY_X] : zero) - w[WY_X]) + ((oz ? wz[WZ_X] : zero) - w[WZ_X]);
-  add[1] = ((ox ? wx[WX_Y] : zero) - w[WX_Y]) + ((oz ? wz[WZ_Y] : zero) - w[WZ_Y]);
-  add[2] = ((ox ? wx[WX_Z] : zero) - w[WX_Z]) + ((oy ? wy[WY_Z] : zero) - w[WY_Z]);
+  add[1] = ((ox ? wx[WX_Y] : bxy) - w[WX_Y]) + ((oz ? wz[WZ_Y] : zero) - w[WZ_Y]);
+  add[2] = ((ox ? wx[WX_Z] : bxz) - w[WX_Z]) + ((oy ? wy[WY_Z] : zero) - w[WY_Z]);
   lamG_out[c3] = o[0] + add[0];
   lamG_out[c3 + 1] = o[1] + add[1];
   lamG_out[c3 + 2] = o[2] + add[2];
@@ -298,10 +302,14 @@ __global__ __launch_bounds__(256) void adj_shell_E(AdjArgs<T> a, const T* __rest
   adj_E_cell<T, 1>(a, i, oy ? j + 1 : j, k, oy ? c3 + sy : c3, vy, wy, false);
   adj_E_cell<T, 2>(a, i, j, oz ? k + 1 : k, oz ? c3 + 3 : c3, vz, wz, false);
   const T zero = T(0);
+  // the last plane of an x-slab: the two entries of the cell above come from the rank above
+  const bool ghost = !ox && a.open_hi && a.wghost;
+  const int64_t gr = ((int64_t)j * a.nz + k) * 2;
+  const T bxy = ghost ? a.wghost[gr] : zero, bxz = ghost ? a.wghost[gr + 1] : zero;
   T add[3];
   add[0] = (w[WY_X] - (oy ? wy[WY_X] : zero)) + (w[WZ_X] - (oz ? wz[WZ_X] : zero));
-  add[1] = (w[WX_Y] - (ox ? wx[WX_Y] : zero)) + (w[WZ_Y] - (oz ? wz[WZ_Y] : zero));
-  add[2] = (w[WX_Z] - (ox ? wx[WX_Z] : zero)) + (w[WY_Z] - (oy ? wy[WY_Z] : zero));
+  add[1] = (w[WX_Y] - (ox ? wx[WX_Y] : bxy)) + (w[WZ_Y] - (oz ? wz[WZ_Y] : zero));
+  add[2] = (w[WX_Z] - (ox ? wx[WX_Z] : bxz)) + (w[WY_Z] - (oy ? wy[WY_Z] : zero));
   lamG_out[c3] = o[0] + add[0];
   lamG_out[c3 + 1] = o[1] + add[1];
   lamG_out[c3 + 2] = o[2] + add[2];
@@ -490,19 +498,51 @@ __global__ __launch_bounds__(256) void adj_shell_faces(AdjArgs<T> a, AdjFaceSet<
   wxy += gx[2]; wxz -= gx[1];
   wyz += gy[0]; wyx -= gy[2];
   wzx += gz[1]; wzy -= gz[0];
+  // across an open face of an x-slab the two entries come from the neighbour rank's plane
+  if (!ox && (PHASE_E ? a.open_hi : a.open_lo) && a.wghost) {
+    const int64_t gr = ((int64_t)j * a.nz + k) * 2;
+    wxy = a.wghost[gr];
+    wxz = a.wghost[gr + 1];
+  }
+  const bool hx = ox || ((PHASE_E ? a.open_hi : a.open_lo) && a.wghost);
   T add[3];
   if (PHASE_E) {
     add[0] = (w[WY_X] - (oy ? wyx : zero)) + (w[WZ_X] - (oz ? wzx : zero));
-    add[1] = (w[WX_Y] - (ox ? wxy : zero)) + (w[WZ_Y] - (oz ? wzy : zero));
-    add[2] = (w[WX_Z] - (ox ? wxz : zero)) + (w[WY_Z] - (oy ? wyz : zero));
+    add[1] = (w[WX_Y] - (hx ? wxy : zero)) + (w[WZ_Y] - (oz ? wzy : zero));
+    add[2] = (w[WX_Z] - (hx ? wxz : zero)) + (w[WY_Z] - (oy ? wyz : zero));
   } else {
     add[0] = ((oy ? wyx : zero) - w[WY_X]) + ((oz ? wzx : zero) - w[WZ_X]);
-    add[1] = ((ox ? wxy : zero) - w[WX_Y]) + ((oz ? wzy : zero) - w[WZ_Y]);
-    add[2] = ((ox ? wxz : zero) - w[WX_Z]) + ((oy ? wyz : zero) - w[WY_Z]);
+    add[1] = ((hx ? wxy : zero) - w[WX_Y]) + ((oz ? wzy : zero) - w[WZ_Y]);
+    add[2] = ((hx ? wxz : zero) - w[WX_Z]) + ((oy ? wyz : zero) - w[WY_Z]);
   }
   lamG_out[c3] = o[0] + add[0];
   lamG_out[c3 + 1] = o[1] + add[1];
   lamG_out[c3 + 2] = o[2] + add[2];
+}
+
+// What a rank sends across an open face of its x-slab in a whole reverse step: the two
+// difference adjoints along x (WX_Y, WX_Z) of every cell of plane `i`, packed (ny, nz, 2) --
+// what pass 1 would have left in work[plane i][..., 0:2], evaluated without its side effects.
+// Undoing the H half step the last plane's go to the rank above (a.lamF = lamH as the step
+// being undone left it), undoing the E half step plane 0's go to the rank below (a.lamF = the
+// new lamE, before any rescaling under absorbing objects).
+template <typename T, bool PHASE_E>
+__global__ __launch_bounds__(256) void adj_pack_plane(AdjArgs<T> a, int i, T* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t plane = (int64_t)a.ny * a.nz;
+  // (no early return: adj_E_cell / adj_H_cell vote across the wave)
+  const bool live = r < plane;
+  const int64_t rc = live ? r : plane - 1;
+  const int j = (int)(rc / a.nz), k = (int)(rc % a.nz);
+  const int64_t c3 = ((int64_t)i * plane + rc) * 3;
+  T lam[3] = {a.lamF[c3], a.lamF[c3 + 1], a.lamF[c3 + 2]};
+  T G[6];
+  if (PHASE_E) adj_E_cell<T, 0>(a, i, j, k, c3, lam, G, false);
+  else adj_H_cell<T, 0>(a, i, j, k, c3, lam, G, false);
+  if (live) {
+    out[r * 2] = G[WX_Y];
+    out[r * 2 + 1] = G[WX_Z];
+  }
 }
 
 // What pass 1 of the E half step does to lamE itself: under absorbing objects, last

@@ -473,9 +473,87 @@ class SlabGrid(Grid):
         if half is not None:      # the adjoint of one hand-driven half step
             (undo_E if half == "E" else undo_H)(0)
             return
+        s = n - 1
+        alt = self._whole_reverse_steps_agreed(lib, n, lamE, lamH)
+        if alt is not None:
+            # pairs of whole reverse steps in stages, first -> second adjoint arrays and back (an
+            # odd first one in the two-pass form): the mirror image of _whole_step
+            try:
+                if n % 2:
+                    undo_H(s)
+                    undo_E(s)
+                    s -= 1
+                first, second = (lamE, lamH), alt[:2]
+                while s >= 1:
+                    self._whole_reverse_step(lib, s, 1, first, second, work, send, from_below, from_above)
+                    self._whole_reverse_step(lib, s - 1, 2, second, first, work, send, from_below, from_above)
+                    s -= 2
+                self.whole_reverse_steps_taken = getattr(self, "whole_reverse_steps_taken", 0) + n - n % 2
+            finally:
+                self._withdraw_adjoint_buffers(lib)
+            return
         for s in range(n - 1, -1, -1):
             undo_H(s)
             undo_E(s)
+
+    def _whole_reverse_steps_agreed(self, lib, n, lamE, lamH):
+        """Collective: second adjoint arrays if every rank's plan can undo whole steps in stages
+        (``fdtdhip_adjoint_step_stage``), else None.  The two ways of sweeping exchange planes
+        at different moments, so all ranks take the same one."""
+        mine, alt = 0, None
+        big = self._adjoint_march_forced() or self.Nx * self.Ny * self.Nz >= 1 << 22
+        if n >= 2 and self._adjoint_second_buffers and big and not self._x_wrap:
+            ptr = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+            pmls = [b for b in self.boundaries if hasattr(b, "thickness") and b._active]
+            alt = (torch.empty_like(lamE), torch.empty_like(lamH),
+                   [(torch.empty_like(b._psiE.detach()), torch.empty_like(b._psiH.detach())) for b in pmls])
+            _lib.check(lib.fdtdhip_plan_set_adjoint_buffers(self._plan, ptr(alt[0]), ptr(alt[1])))
+            for b, (ae, ah) in zip(pmls, alt[2]):
+                _lib.check(lib.fdtdhip_plan_set_pml_adjoint_buffers(self._plan, b._native_id, ptr(ae), ptr(ah)))
+            mine = _lib.check(lib.fdtdhip_plan_adjoint_whole_steps(self._plan))
+        if self._world > 1:
+            on_device = self._backend_name == "nccl"
+            flag = torch.tensor([mine], device=bd.device if on_device else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._group)
+            mine = int(flag.item())
+        if not mine:
+            if alt is not None:
+                self._withdraw_adjoint_buffers(lib)
+            return None
+        return alt
+
+    def _withdraw_adjoint_buffers(self, lib):
+        _lib.check(lib.fdtdhip_plan_set_adjoint_buffers(self._plan, None, None))
+        for b in self.boundaries:
+            if hasattr(b, "thickness") and b._active:
+                _lib.check(lib.fdtdhip_plan_set_pml_adjoint_buffers(self._plan, b._native_id, None, None))
+
+    def _whole_reverse_step(self, lib, s, flip, cur, new, work, send, from_below, from_above):
+        """One reverse step from the adjoint arrays ``cur`` = (lamE, lamH) into ``new`` in four
+        pieces around its two plane exchanges.  Undoing the H half step, plane 0 gathers from
+        the last plane of the rank below: every rank packs the two difference adjoints along x
+        of its last plane (they depend on lamH as it stands) and sends them upwards first; the
+        cells that do not wait for them are undone meanwhile, with half of the marching kernel.
+        Undoing the E half step, the last plane gathers from plane 0 of the rank above, whose
+        new lamE exists once its stage 1 has run: packed, sent downwards behind the other half
+        of the marching kernel."""
+        r, p, plan = self._rank, self._world, self._plan
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        args = (flip, ptr(cur[0]), ptr(cur[1]), ptr(new[0]), ptr(new[1]), ptr(work))
+        if r < p - 1:
+            _lib.check(lib.fdtdhip_adjoint_pack_plane(plan, 0, s, flip, ptr(cur[0]), ptr(cur[1]), ptr(send)))
+        ex = self._start_exchange(send if r < p - 1 else None, r + 1, from_below, r - 1)
+        _lib.check(lib.fdtdhip_adjoint_step_stage(plan, s, 0, *args, None))
+        if ex is not None:
+            ex.wait()
+        _lib.check(lib.fdtdhip_adjoint_step_stage(plan, s, 1, *args, ptr(from_below)))
+        if r > 0:
+            _lib.check(lib.fdtdhip_adjoint_pack_plane(plan, 1, s, flip, ptr(new[0]), ptr(cur[1]), ptr(send)))
+        ex = self._start_exchange(send if r > 0 else None, r - 1, from_above, r + 1)
+        _lib.check(lib.fdtdhip_adjoint_step_stage(plan, s, 2, *args, None))
+        if ex is not None:
+            ex.wait()
+        _lib.check(lib.fdtdhip_adjoint_step_stage(plan, s, 3, *args, ptr(from_above)))
 
     def backward(self, loss):
         """Back-propagate this rank's part of the loss (the total loss is the sum over

@@ -393,6 +393,31 @@ int fdtdhip_adjoint_gather(fdtdhip_plan* plan, int phase_E, void* lamE, void* la
 int fdtdhip_adjoint_post_stage(fdtdhip_plan* plan, int phase_E, int64_t step, int stage, void* lamE,
                                void* lamH);
 
+/* Whole reverse steps on an x-slab, in stages around the two plane exchanges of a step: the
+ * mirror image of fdtdhip_step_stage (no reference counterpart).  With the second adjoint
+ * arrays of fdtdhip_plan_set_adjoint_buffers / fdtdhip_plan_set_pml_adjoint_buffers set,
+ * fdtdhip_plan_adjoint_whole_steps tells (1 / 0) whether the plan can take them.  One reverse
+ * step from (lamE0, lamH0) to (lamE1, lamH1), `flip` = 1 when these are the first and the
+ * second arrays (memory-variable adjoints first -> second) and 2 for the way back, `step` the
+ * row of the curl traces:
+ *   fdtdhip_adjoint_pack_plane(phase_E = 0)  the (ny, nz, 2) plane the rank ABOVE needs, from
+ *            lamH0 of the last plane; the caller sends it and receives the rank below's;
+ *   stage 0  H half step undone next to PMLs, objects and the high face, first half of the
+ *            marching kernel over the other cells -- needs no plane;
+ *   stage 1  H half step undone in plane 0: `ghost` = the plane received from the rank below;
+ *   fdtdhip_adjoint_pack_plane(phase_E = 1)  the plane the rank BELOW needs, from the new
+ *            lamE1 of plane 0; sent, and the rank above's received;
+ *   stage 2  second half of the marching kernel, E half step undone away from the last plane;
+ *   stage 3  E half step undone in the last plane: `ghost` = the plane received from above.
+ * A stage without an open face on its side ignores `ghost` (NULL).  Results equal the
+ * two-pass sweep of fdtdhip_adjoint_cells / fdtdhip_adjoint_gather.  `work`: cells*6 elements
+ * of scratch.  Take steps in pairs so that the result ends in the first arrays. */
+int fdtdhip_plan_adjoint_whole_steps(fdtdhip_plan* plan);
+int fdtdhip_adjoint_pack_plane(fdtdhip_plan* plan, int phase_E, int64_t step, int flip, void* lamE,
+                               void* lamH, void* out);
+int fdtdhip_adjoint_step_stage(fdtdhip_plan* plan, int64_t step, int stage, int flip, void* lamE0,
+                               void* lamH0, void* lamE1, void* lamH1, void* work, const void* ghost);
+
 /* Optional: prove that the material arrays need not be read.  The reference fills
  * inverse_permittivity and inverse_permeability with one value (fdtd/grid.py:135-151)
  * and an object zeroes the inverse permittivity in its box (fdtd/objects.py:90), so

@@ -310,6 +310,30 @@ def test_staged_steps_over_rccl_equal_half_steps_bitwise():
     assert sums["staged"] == sums["half steps"], sums
 
 
+@pytest.mark.gpu
+def test_staged_reverse_steps_over_rccl_equal_the_two_pass_sweep_bitwise():
+    """The same for the reverse sweep: a recorded run of that self-neighbouring slab with a
+    learnable box, back-propagated by whole reverse steps in stages (planes of difference
+    adjoints packed by the library, sent over RCCL around the four stages) and, in a second
+    process, by the two-pass sweep that exchanges a plane between its passes: the checksum of
+    the gradients' bit patterns (dL/dE0, dL/dtensor) must be the same."""
+    import subprocess
+
+    tool = os.path.join(os.path.dirname(HERE), "tools", "slab_step_cost.py")
+    sums = {}
+    for mode, env in (("staged", {}), ("two passes", {"FDTDHIP_ADJ_MARCH": "0"})):
+        port = str(slab_support.free_port())
+        base = {k: v for k, v in os.environ.items() if k not in ("FDTDHIP_FUSED", "FDTDHIP_ADJ_MARCH")}
+        done = subprocess.run([sys.executable, tool, "4", "small", "adjoint", "12"], capture_output=True,
+                              text=True, timeout=280, env=dict(base, MASTER_PORT=port, **env))
+        assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-3000:]
+        line = [ln for ln in done.stdout.splitlines() if ln.startswith("gradient checksum")][0]
+        taken = int(done.stdout.split("whole reverse steps taken")[1].split()[0])
+        assert (taken > 0) == (mode == "staged"), done.stdout[-500:]
+        sums[mode] = line
+    assert sums["staged"] == sums["two passes"], sums
+
+
 def test_partition_arithmetic():
     from fdtd_amd.parallel import SlabGrid
 
@@ -565,6 +589,32 @@ def test_random_scenes_slab_gradients_gpu(tmp_path):
     seeds, bad = fuzz_slab_adjoint.run(3, 100, 90, str(tmp_path / "adj.npz"))
     assert len(seeds) >= 20
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_random_scenes_slab_gradients_whole_steps_gpu(tmp_path, monkeypatch):
+    """The same with recorded runs advanced and reverse sweeps undone by whole steps in stages
+    around the plane exchanges (fdtdhip_step_stage, fdtdhip_adjoint_step_stage; the switches
+    apply them at any size the plans allow, the default is large 3-D slabs): on two, three and
+    five ranks, larger extents too."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_slab_adjoint as fz
+
+    for name in ("FDTDHIP_ADJ_MARCH", "FDTDHIP_ADJ_DIRECT", "FDTDHIP_FUSED"):
+        monkeypatch.setenv(name, "2")
+    undone = advanced = 0
+    for world, first, count, extra in ((2, 7000, 40, {}), (3, 7100, 40, {}), (2, 7200, 12, {"FUZZ_BIG": "1"}),
+                                       (5, 7300, 30, {"FUZZ_THIN_X": "5"})):
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
+        seeds, bad = fz.run(world, first, count, str(tmp_path / f"adj_{world}_{first}.npz"))
+        for k in extra:
+            monkeypatch.delenv(k)
+        assert len(seeds) >= 6, (world, first, len(seeds))
+        assert not bad, bad
+        undone += fz.WHOLE_REVERSE_STEPS
+        advanced += fz.WHOLE_FORWARD_STEPS
+    assert undone >= 100 and advanced >= 60, (undone, advanced)
 
 
 @pytest.mark.gpu

@@ -62,7 +62,14 @@ def one(seed, fdtd, factory, backward):
     torch.cuda.synchronize()
     obj = [t for k, t, _, _ in made if k == "learnable"][0]
     g = obj.inverse_permittivity.grad if obj.Nx > 0 else None
+    global WHOLE_REVERSE_STEPS, WHOLE_FORWARD_STEPS
+    WHOLE_REVERSE_STEPS += getattr(grid, "whole_reverse_steps_taken", 0)
+    WHOLE_FORWARD_STEPS += getattr(grid, "whole_steps_taken", 0)
     return loss.item(), (g.cpu().numpy() if g is not None else None)
+
+
+WHOLE_REVERSE_STEPS = 0   # steps this process undid / advanced by whole steps in stages (slabs)
+WHOLE_FORWARD_STEPS = 0
 
 
 def worker(rank, world, port, seeds, out):
@@ -83,6 +90,8 @@ def worker(rank, world, port, seeds, out):
                 res[f"loss{seed}"] = sum(p[0] for p in parts)
                 res[f"grad{seed}"] = np.concatenate([p[1] for p in parts if p[1] is not None], axis=0)
         if rank == 0:
+            res["whole_reverse_steps"] = WHOLE_REVERSE_STEPS
+            res["whole_forward_steps"] = WHOLE_FORWARD_STEPS
             np.savez(out, **res)
     finally:
         dist.destroy_process_group()
@@ -92,6 +101,9 @@ def run(world, first, count, out):
     seeds = [s for s in range(first, first + count) if usable(scene_for(s), world)]
     mp.spawn(worker, args=(world, slab_support.free_port(), seeds, out), nprocs=world, join=True)
     z = np.load(out)
+    global WHOLE_REVERSE_STEPS, WHOLE_FORWARD_STEPS
+    WHOLE_REVERSE_STEPS, WHOLE_FORWARD_STEPS = int(z["whole_reverse_steps"]), int(z["whole_forward_steps"])
+    taken = (WHOLE_REVERSE_STEPS, WHOLE_FORWARD_STEPS)
     import fdtd_amd as fdtd
 
     fdtd.set_backend("hip.float64", device=0)
@@ -108,6 +120,7 @@ def run(world, first, count, out):
             errs["grad"] = e
         if errs:
             bad[seed] = errs
+    WHOLE_REVERSE_STEPS, WHOLE_FORWARD_STEPS = taken    # (rank 0 of the slab run, not the undivided grids)
     return seeds, bad
 
 
@@ -116,5 +129,6 @@ if __name__ == "__main__":
     seeds, bad = run(world, first, count, f"/tmp/fuzz_slab_adj_{os.getpid()}.npz")
     for seed, errs in bad.items():
         print(f"seed {seed}: {errs}\n   {scene_for(seed)}")
-    print(f"x{world}: {len(seeds)} scenes, {len(bad)} differ from the undivided grid")
+    print(f"x{world}: {len(seeds)} scenes, {len(bad)} differ from the undivided grid; rank 0 undid "
+          f"{WHOLE_REVERSE_STEPS} steps and advanced {WHOLE_FORWARD_STEPS} as whole steps in stages")
     sys.exit(1 if bad else 0)

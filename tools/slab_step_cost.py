@@ -8,6 +8,12 @@ interior / boundary-plane split); default: whole steps in stages.
 
     python tools/slab_step_cost.py [steps] [workload: m4 | m4end (the first slab: a PML on its
                                                      low x face, one neighbour) | m3v | small]
+                                   [adjoint [recorded steps]]
+
+`adjoint`: then a recorded run (a learnable 32^3 box in the middle of the slab) and its reverse
+sweep, with the plane exchanges of the real schedule: milliseconds per reverse step and a
+checksum of the gradients' bit patterns.  FDTDHIP_ADJ_MARCH=0: the two-pass sweep, one plane
+exchanged per half step between its passes; default: whole reverse steps in stages.
 """
 import os
 import sys
@@ -71,6 +77,10 @@ if workload in ("m4", "m4end"):
                 (slice(None), slice(None), slice(0, 10)), (slice(None), slice(None), slice(-10, None))):
         g[key] = fdtd.PML()
 g[shape[0] // 2, shape[1] // 2, shape[2] // 2] = fdtd.PointSource(period=20)
+adjoint = len(sys.argv) > 3 and sys.argv[3] == "adjoint"
+if adjoint:
+    m = [n // 2 for n in shape]
+    g[m[0] - 16:m[0] + 16, m[1] + 20:m[1] + 52, m[2] - 16:m[2] + 16] = fdtd.LearnableAnisotropicObject(permittivity=2.5)
 gen = torch.Generator(device=g.E.device).manual_seed(1)
 with torch.no_grad():
     for f in (g.E, g.H):
@@ -91,4 +101,31 @@ print(f"{workload} interior slab, FDTDHIP_FUSED={os.environ.get('FDTDHIP_FUSED',
       f"{(t2 - t0) / steps * 1e3:.3f} ms/step = {cells * steps / (t2 - t0) / 1e9:.1f} Gcells/s, "
       f"host enqueue {(t1 - t0) / steps * 1e3:.3f} ms/step, whole steps taken {g.whole_steps_taken}",
       flush=True)
+if adjoint:
+    nb = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+    for _ in range(2):      # the first pass warms up allocator and code objects
+        g.objects[0].inverse_permittivity.grad = None
+        E0 = g.E.detach().clone().requires_grad_(True)
+        g.E = E0
+        g.H = g.H.detach()
+        for b in g.boundaries:      # the memory variables of the pass before belong to its graph
+            if getattr(b, "_psiE", None) is not None:
+                b._psiE, b._psiH = b._psiE.detach(), b._psiH.detach()
+        taken0 = getattr(g, "whole_reverse_steps_taken", 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g.run(nb)
+        loss = (g.E ** 2).sum() + (g.H ** 2).sum()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        g.backward(loss)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+    grad = g.objects[0].inverse_permittivity.grad
+    gbits = int(E0.grad.view(torch.int32).to(torch.int64).sum()) ^ (int(grad.view(torch.int32).to(torch.int64).sum()) << 1)
+    print(f"gradient checksum {gbits:#x}, |dL/dE0| {float(E0.grad.norm()):.6e}, |dL/dtensor| {float(grad.norm()):.6e}")
+    print(f"{workload} interior slab, FDTDHIP_ADJ_MARCH={os.environ.get('FDTDHIP_ADJ_MARCH', 'default')}: recorded forward "
+          f"{(t1 - t0) / nb * 1e3:.3f} ms/step, backward {(t2 - t1) / nb * 1e3:.3f} ms/step = "
+          f"{cells * nb / (t2 - t1) / 1e9:.1f} Gcells/s, whole reverse steps taken "
+          f"{getattr(g, 'whole_reverse_steps_taken', 0) - taken0}", flush=True)
 dist.destroy_process_group()
