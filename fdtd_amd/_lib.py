@@ -44,6 +44,7 @@ PROTOTYPES = {
     "fdtdhip_plan_link_soft_source": (_i, [_p, _i, _i]),
     "fdtdhip_plan_set_soft_source_io": (_i, [_p, _i, _p, _p, _p, _i64]),
     "fdtdhip_plan_set_soft_source_adjoint": (_i, [_p, _i, _i64]),
+    "fdtdhip_plan_set_soft_source_adjoint_below": (_i, [_p, _i, _p]),
     "fdtdhip_adjoint_post_stage": (_i, [_p, _i, _i64, _i, _p, _p]),
     "fdtdhip_plan_add_modulated_source": (_i, [_p, _pi32, _i, _i]),
     "fdtdhip_plan_set_modulated_source": (_i, [_p, _i, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]),

@@ -303,6 +303,14 @@ int fdtdhip_plan_set_soft_source_adjoint(fdtdhip_plan* p, int id, int64_t q0) {
   return 0;
 }
 
+int fdtdhip_plan_set_soft_source_adjoint_below(fdtdhip_plan* p, int id, void* lamH_below) {
+  if (!p) return fail(-1, "null plan");
+  if (id < 0 || id >= (int)p->sources.size() || p->sources[id].kind != FDTDHIP_SRC_SOFT_POINT)
+    return fail(-1, "not a soft source");
+  p->sources[id].adj_below = lamH_below;
+  return 0;
+}
+
 int fdtdhip_plan_add_modulated_source(fdtdhip_plan* p, const int32_t box[6], int comp,
                                       int channels) {
   if (!p) return fail(-1, "null plan");

@@ -163,13 +163,15 @@ int adjoint_post(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, int stage) {
       // the voltage added to E is a constant plus impedance * (loop current of the step
       // before): its adjoint goes to the adjoint of H as the H half step before left it
       if (!phaseE || s.nwave < 0 || !(s.impedance > 0)) continue;
-      if (p->H_below || p->E_above)
-        return fail(-1, "the adjoint does not cover a source fed back from a current detector on x-slabs");
+      // (on an x-slab with the cell on plane 0 the loop reaches into another rank's plane)
+      if (p->H_below && s.elem0 < (int64_t)p->ny * p->nz * 3 && !s.adj_below)
+        return fail(-1, "soft source on plane 0 of an x-slab: fdtdhip_plan_set_soft_source_adjoint_below "
+                        "names the plane that collects the terms of the rank below");
       if (s.adj_q0 < 0)
         return fail(-1, "soft source: fdtdhip_plan_set_soft_source_adjoint names the time step of the adjoint's row 0");
       if (s.adj_q0 + p->trace_cursor <= 0) continue;   // no current yet at time step 0
       hipLaunchKernelGGL((adj_source_soft_point<T>), dim3(1), dim3(1), 0, p->stream, (const T*)lamE,
-                         lamH, s.elem0, p->nx, p->ny, p->nz, s.impedance, s.spacing);
+                         lamH, s.elem0, p->nx, p->ny, p->nz, s.impedance, s.spacing, (T*)s.adj_below);
       continue;
     }
     if (s.kind == FDTDHIP_SRC_MODULATED_BOX && phaseE && s.modP) {

@@ -127,6 +127,7 @@ struct SourceH {
   char *vin = nullptr, *vout = nullptr;
   int64_t vcap = 0, vused = 0;
   int64_t adj_q0 = -1;         // time step of row 0 of the adjoint calls (fdtdhip_plan_set_soft_source_adjoint)
+  void* adj_below = nullptr;   // x-slabs: (ny,nz,3) plane that collects the adjoint terms of plane x - 1
 };
 
 struct DetH {

@@ -597,26 +597,35 @@ __global__ void adj_periodic_copy(T* lam, int nx, int ny, int nz, int axis, int 
 // form of H around the cell that detect_current evaluates -- with the first layer's Hy
 // difference counted in both layers and Python's wrap-around for index -1.  One lane;
 // coinciding cells (an extent of one) just receive several of the terms.
+// `below`: on an x-slab whose plane 0 holds the cell, the plane x - 1 belongs to another rank
+// (the one below, or -- wrapping around -- the last one): its terms are ADDED to this
+// (ny, nz, 3) plane instead, which the caller sends there.
 template <typename T>
 __global__ void adj_source_soft_point(const T* lamE, T* lamH, int64_t elem, int nx, int ny, int nz,
-                                      double impedance, double spacing) {
+                                      double impedance, double spacing, T* below) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   const int64_t cell = elem / 3;
   const int pz = (int)(cell % nz), py = (int)((cell / nz) % ny), px = (int)(cell / ((int64_t)nz * ny));
   const int xm = px == 0 ? nx - 1 : px - 1;
   const int ym = py == 0 ? ny - 1 : py - 1;
   const int zm = pz == 0 ? nz - 1 : pz - 1;
+  const bool away = px == 0 && below != nullptr;
   auto at = [&](int i, int j, int k, int c) -> T& {
     return lamH[(((int64_t)i * ny + j) * nz + k) * 3 + c];
+  };
+  // the cell at plane x - 1 (told apart by name, not by index: on a slab of one plane xm == px)
+  auto at_xm = [&](int j, int k, int c) -> T& {
+    if (away) return below[((int64_t)j * nz + k) * 3 + c];
+    return lamH[(((int64_t)xm * ny + j) * nz + k) * 3 + c];
   };
   // adjoint of the current, then of each of its two layers (I = (cur1 + cur2) / 2), times
   // the spacing every difference was scaled with
   const T g = (T)((double)lamE[elem] * (impedance / spacing));
   const T h = g / T(2) * (T)spacing;
   at(px, ym, pz, 0) += h; at(px, py, pz, 0) -= h;            // layer pz, Hx
-  at(px, py, pz, 1) += h + h; at(xm, py, pz, 1) -= h + h;    // layer pz, Hy: in both currents
+  at(px, py, pz, 1) += h + h; at_xm(py, pz, 1) -= h + h;     // layer pz, Hy: in both currents
   at(px, ym, zm, 0) += h; at(px, py, zm, 0) -= h;            // layer pz - 1, Hx
-  at(px, py, zm, 1) += h; at(xm, py, zm, 1) -= h;            // layer pz - 1, Hy
+  at(px, py, zm, 1) += h; at_xm(py, zm, 1) -= h;             // layer pz - 1, Hy
 }
 
 template <typename T>

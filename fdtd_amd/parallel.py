@@ -460,16 +460,45 @@ class SlabGrid(Grid):
             _lib.check(lib.fdtdhip_adjoint_gather(plan, 0, ptr(lamE), ptr(lamH), ptr(work),
                                                   ptr(from_below)))
 
+        # a source fed back from its loop current on the first plane of a slab: the loop reads H
+        # of plane x - 1 (reference fdtd/detectors.py:452-459), another rank's last plane, and the
+        # adjoint of Ez at the cell flows back there -- collected in a plane of its own, passed
+        # down the ring (as the forward pass passes the H plane up) and added on arrival
+        soft = [src for src in self.sources if hasattr(src, "current_detector") and src.impedance > 0]
+        counts = self._plane_counts()
+        firsts = {sum(counts[:q]) for q in range(p)}
+        soft_cross = p > 1 and any(self._cell_index(src.x, self.Nx_global) in firsts for src in soft)
+        below = ring_in = None
+        if soft_cross:
+            below, ring_in = bd.zeros((self.Ny, self.Nz, 3)), bd.zeros((self.Ny, self.Nz, 3))
+            for src in soft:
+                if src._native_id is not None and self._local_x(self._cell_index(src.x, self.Nx_global)) == 0:
+                    _lib.check(lib.fdtdhip_plan_set_soft_source_adjoint_below(plan, src._native_id, ptr(below)))
+
         def undo_E(s):
             if wrap:
                 undo_wrap(1, s, lamE)
             _lib.check(lib.fdtdhip_adjoint_cells(plan, 1, s, ptr(lamE), ptr(lamH), ptr(work)))
+            if soft_cross:
+                ex = self._start_exchange(below, (r - 1) % p, ring_in, (r + 1) % p)
+                ex.wait()
+                lamH[-1] += ring_in
+                below.zero_()
             ex = self._start_exchange(across(planes[0]) if r > 0 else None, r - 1, from_above, r + 1)
             if ex is not None:
                 ex.wait()
             _lib.check(lib.fdtdhip_adjoint_gather(plan, 1, ptr(lamE), ptr(lamH), ptr(work),
                                                   ptr(from_above)))
 
+        try:
+            self._reverse_sweep(lib, n, lamE, lamH, work, half, undo_E, undo_H, send, from_below, from_above)
+        finally:
+            if soft_cross:
+                for src in soft:
+                    if src._native_id is not None:
+                        _lib.check(lib.fdtdhip_plan_set_soft_source_adjoint_below(plan, src._native_id, None))
+
+    def _reverse_sweep(self, lib, n, lamE, lamH, work, half, undo_E, undo_H, send, from_below, from_above):
         if half is not None:      # the adjoint of one hand-driven half step
             (undo_E if half == "E" else undo_H)(0)
             return

@@ -417,14 +417,10 @@ class SoftArbitraryPointSource:
     the rank whose slab holds the cell runs the source and fills the two lists; on the other
     ranks they stay empty."""
 
-    @property
-    def _no_autograd(self):
-        """Differentiable runs carry the feedback (the adjoint of Ez at the cell reaches the
-        adjoint of H around it, as on the reference's tape); the waveform is a constant.  Not
-        on a grid of several x-slabs."""
-        if getattr(self.grid, "_world", 1) > 1:
-            return "a source fed back from its current detector on x-slabs"
-        return None
+    # Differentiable runs carry the feedback (the adjoint of Ez at the cell reaches the adjoint
+    # of H around it, as on the reference's tape; on x-slabs also across a slab face, see
+    # SlabGrid._native_adjoint); the waveform is a constant.
+    _no_autograd = None
 
     def __init__(self, waveform_array, name: str = None, impedance: float = 0.0):
         self.grid = None

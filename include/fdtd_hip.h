@@ -186,13 +186,20 @@ int fdtdhip_plan_set_modulated_source(fdtdhip_plan* plan, int id, const void* P,
  * sources.py:720 is a function of H): fdtdhip_plan_set_soft_source_adjoint, before
  * fdtdhip_adjoint_run / _cells, names the time step q0 of the adjoint's step 0 (at time step 0
  * there is no current); the adjoint of E at the cell then reaches the adjoint of H around
- * it.  Not on x-slabs.  The waveform is a constant (no gradient for it). */
+ * it.  The waveform is a constant (no gradient for it).  On an x-slab whose plane 0 holds the
+ * cell the loop reaches into plane x - 1 of another rank (the one below; for plane 0 of the
+ * simulation, wrapping around as the detector does, the last one):
+ * fdtdhip_plan_set_soft_source_adjoint_below names a device (ny, nz, 3) plane to which the
+ * terms of that plane are ADDED instead; the caller clears it, sends it to that rank after
+ * fdtdhip_adjoint_cells(phase_E = 1) and the receiver adds it to the last plane of its lamH
+ * before its fdtdhip_adjoint_gather.  NULL: an undivided grid (the wrap-around stays inside). */
 int fdtdhip_plan_add_soft_source(fdtdhip_plan* plan, const int32_t cell[3], const double* waveform,
                                  int64_t nwave, double impedance, double spacing);
 int fdtdhip_plan_link_soft_source(fdtdhip_plan* plan, int id, int detector_id);
 int fdtdhip_plan_set_soft_source_io(fdtdhip_plan* plan, int id, const void* prev_current,
                                     void* vin_out, void* vout_out, int64_t capacity);
 int fdtdhip_plan_set_soft_source_adjoint(fdtdhip_plan* plan, int id, int64_t q0);
+int fdtdhip_plan_set_soft_source_adjoint_below(fdtdhip_plan* plan, int id, void* lamH_below);
 
 /* Detector over n points.  FDTDHIP_DET_CELLS: cells = HOST 3*n ints; each
  * reading is (n,3) (reference fdtd/detectors.py:114-124, 241-265).

@@ -228,9 +228,8 @@ def _adjoint_worker(rank, world, port, scene_name, out, by_hand=False):
         dist.destroy_process_group()
 
 
-# (a source fed back from its loop current is differentiable on undivided grids only)
 @pytest.mark.gpu
-@pytest.mark.parametrize("scene_name", sorted(set(scenes.ADJOINT_SCENES) - {"adjoint_softfeed"}))
+@pytest.mark.parametrize("scene_name", sorted(scenes.ADJOINT_SCENES))
 def test_slab_gradients_match_reference_autograd(scene_name, tmp_path):
     """Differentiable run on two slabs (two ranks sharing the GPU, planes of difference
     adjoints exchanged per reverse half step) against the gradients the reference's
@@ -589,6 +588,25 @@ def test_random_scenes_slab_gradients_gpu(tmp_path):
     seeds, bad = fuzz_slab_adjoint.run(3, 100, 90, str(tmp_path / "adj.npz"))
     assert len(seeds) >= 20
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_random_scenes_slab_gradients_with_feedback_sources_gpu(tmp_path, monkeypatch):
+    """Differentiable runs with sources fed back from their loop current (reference
+    fdtd/sources.py:708-737) on slabs: the adjoint of Ez at the cell reaches the adjoint of H
+    around it, also in the last plane of the rank below when the cell sits on the first plane
+    of a slab (slabs of one or two planes: nearly every source does), wrapping around from the
+    first rank to the last as the detector's index -1 does."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_slab_adjoint as fz
+
+    monkeypatch.setenv("FUZZ_EXTRAS", "1")
+    seeds, bad = fz.run(3, 8000, 40, str(tmp_path / "adj_soft3.npz"))
+    assert len(seeds) >= 15 and not bad, bad
+    monkeypatch.setenv("FUZZ_THIN_X", "5")
+    seeds, bad = fz.run(5, 8100, 45, str(tmp_path / "adj_soft5.npz"))
+    assert len(seeds) >= 15 and not bad, bad
+    assert any(it[0] == "soft" and it[2]["impedance"] > 0 for s in seeds for it in fz.scene_for(s)["items"])
 
 
 @pytest.mark.gpu

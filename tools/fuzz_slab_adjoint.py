@@ -28,7 +28,9 @@ import slab_support  # noqa: E402
 
 def scene_for(seed):
     # FUZZ_THIN_X=n: n to n + 2 planes along x (one- and two-plane slabs on n ranks)
-    scene = fuzz_scenes.random_scene(seed, thin_x=int(os.environ.get("FUZZ_THIN_X", "0")))
+    # FUZZ_EXTRAS=1: sources fed back from their loop current (and direction-vector point sources)
+    scene = fuzz_scenes.random_scene(seed, thin_x=int(os.environ.get("FUZZ_THIN_X", "0")),
+                                     big=bool(os.environ.get("FUZZ_BIG")), extras=bool(os.environ.get("FUZZ_EXTRAS")))
     rs = np.random.RandomState(seed + 77)
     box = fuzz_scenes._box(rs, scene["grid"]["shape"], max_frac=0.6)
     scene["items"].append(("learnable", box, dict(permittivity=float(1.5 + rs.rand())),
