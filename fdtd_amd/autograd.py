@@ -93,7 +93,7 @@ class _Run(torch.autograd.Function):
         psis = [t.detach().clone() for t in rest[k:]]
         for n_p, p in enumerate(pmls):
             p._psiE, p._psiH = psis[2 * n_p], psis[2 * n_p + 1]
-        lib = grid._ensure_plan()          # binds the fresh state tensors
+        lib = grid._ensure_plan(steps=n)   # binds the fresh state tensors
         plan = grid._plan
         traces, etraces = [], []
         for o in objs:

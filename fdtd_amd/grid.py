@@ -270,7 +270,9 @@ class Grid:
             sig.append(tuple(t._signature() for t in group))
         return tuple(sig)
 
-    def _ensure_plan(self):
+    def _ensure_plan(self, steps=1):
+        """The native plan, bound to the grid's current tensors and components.  ``steps``:
+        how many steps the caller is about to take (see ``_scan_materials``)."""
         if bd.staging:
             raise RuntimeError(
                 "this grid lives in host staging memory: time stepping needs the hip "
@@ -309,7 +311,7 @@ class Grid:
         _lib.check(lib.fdtdhip_plan_set_stream(self._plan, _stream_ptr(bd.device)))
         _lib.check(lib.fdtdhip_plan_set_fields(
             self._plan, E.data_ptr(), H.data_ptr(), ie.data_ptr(), im.data_ptr()))
-        self._scan_materials(lib, ie, im)
+        self._scan_materials(lib, ie, im, steps)
         for group in (self.objects, self.boundaries):
             for o in group:
                 refresh = getattr(o, "_native_refresh", None)
@@ -334,31 +336,50 @@ class Grid:
         return lib
 
     _MAX_MATERIAL_SCANS = 4
+    _MATERIAL_RECHECK_STEPS = 16
 
-    def _scan_materials(self, lib, ie, im):
+    def _scan_materials(self, lib, ie, im, steps=1):
         """Let the library find out whether the material arrays are constant outside
         the objects (it then stops reading them).  Every in-place write to a tensor
         bumps its version counter, so a changed array is scanned again before the
         next half step; arrays that keep changing are scanned a few times and then
-        simply read by the kernels.  Writes that bypass the counter (``tensor.data``,
-        foreign code holding the pointer) must be followed by ``materials_changed()``."""
+        simply read by the kernels.
+
+        Writes that bypass the counter (``tensor.data``, DLPack, foreign code holding the
+        pointer) are caught by scanning again: while constants are in use, a call that
+        advances ``_MATERIAL_RECHECK_STEPS`` steps or more re-verifies the arrays first, and
+        shorter calls (single steps, half steps) do so once that many steps have gone by
+        since the last scan -- a scan reads both arrays once, half of what a step moves.  A
+        run of 16 steps or more therefore never uses stale constants; hand-driven stepping
+        may for at most 15 steps, unless ``materials_changed()`` is called."""
         # (the tensors themselves are part of the key, held weakly: a re-bound array can land
         # on the address of the one it replaced, with the same version count)
         key = (ie.data_ptr(), ie._version, im.data_ptr(), im._version)
         last = getattr(self, "_materials_key", None)
         same = last is not None and last[0] == key and last[1]() is ie and last[2]() is im
         if same:
+            if not getattr(self, "_materials_mask", 0) or \
+                    getattr(self, "_material_scans", 0) >= self._MAX_MATERIAL_SCANS:
+                return            # no constants in use: the kernels read the arrays
+            gone = getattr(self, "_steps_since_scan", 0)
+            if steps < self._MATERIAL_RECHECK_STEPS and gone + steps <= self._MATERIAL_RECHECK_STEPS:
+                self._steps_since_scan = gone + steps
+                return
+            self._materials_mask = _lib.check(lib.fdtdhip_plan_scan_materials(self._plan, 1))
+            self._steps_since_scan = steps
             return
         self._materials_key = (key, weakref.ref(ie), weakref.ref(im))
         scans = getattr(self, "_material_scans", 0)
         if last is not None:  # the arrays changed under an unchanged plan
             self._material_scans = scans = scans + 1
-        _lib.check(lib.fdtdhip_plan_scan_materials(
+        self._materials_mask = _lib.check(lib.fdtdhip_plan_scan_materials(
             self._plan, 1 if scans < self._MAX_MATERIAL_SCANS else 0))
+        self._steps_since_scan = steps
 
     def materials_changed(self):
         """Tell the grid that inverse_permittivity / inverse_permeability were written
-        to in a way torch does not see; they are examined again before the next step."""
+        to in a way torch does not see; they are examined again before the next step
+        (without this call: within ``_MATERIAL_RECHECK_STEPS`` steps, see ``_scan_materials``)."""
         self._materials_key = None
         self._material_scans = 0
 
@@ -482,7 +503,7 @@ class Grid:
             return
         if n >= 2:
             self._provide_step_buffers()
-        lib = self._ensure_plan()
+        lib = self._ensure_plan(steps=n)
         self._native_run(lib, n)
         self.time_steps_passed += n
 

@@ -42,7 +42,7 @@ class _NativeEngine:
         self.grid = grid
 
     def prepare(self, n=1):
-        self.lib = self.grid._ensure_plan()
+        self.lib = self.grid._ensure_plan(steps=n)
         self.plan = self.grid._plan
         self.grid._prepare_sources(self.lib, n)
 

@@ -111,6 +111,35 @@ def test_material_write_is_noticed():
     assert rel_l2(host(g.E), o.E) <= 1e-12 and rel_l2(host(g.H), o.H) <= 1e-12
 
 
+def test_material_write_that_torch_cannot_see_is_caught_by_the_next_long_run():
+    """A write through ``tensor.data`` bumps no version counter.  While constants are in use
+    the grid scans its material arrays again at the start of every call that advances 16
+    steps or more (and of shorter calls once 16 steps have gone by since the last scan), so
+    such a run gives the reference's fields without ``materials_changed()``."""
+    fdtd.set_backend("hip.float64")
+    shape = (12, 70, 64)
+    g, o = fdtd.Grid(shape), orc.OracleGrid(shape)
+    g[6, 35, 32] = fdtd.PointSource(period=9)
+    o.add_point_source((6, 35, 32), period=9)
+    g.run(20, progress_bar=False); o.run(20)
+    assert _lib.load().fdtdhip_plan_scan_materials(g._plan, 1) == 3    # constants in use
+    g.inverse_permittivity.data[5:8, 30:40, 28:36, :] = 0.4
+    o.inverse_permittivity[5:8, 30:40, 28:36, :] = 0.4
+    g.inverse_permeability.data[4:9, 33:37, 30:34, 1] *= 0.9
+    o.inverse_permeability[4:9, 33:37, 30:34, 1] *= 0.9
+    g.run(16, progress_bar=False); o.run(16)
+    assert rel_l2(host(g.E), o.E) <= 1e-12 and rel_l2(host(g.H), o.H) <= 1e-12
+    # single steps: noticed once 16 of them have gone by since the last scan
+    h = fdtd.Grid(shape)
+    h[6, 35, 32] = fdtd.PointSource(period=9)
+    h.run(3, progress_bar=False)
+    assert h._materials_mask == 3
+    h.inverse_permittivity.data[5:8, 30:40, 28:36, :] = 0.4
+    for _ in range(17):
+        h.run(1, progress_bar=False)
+    assert h._materials_mask == 2      # the inverse permittivity is read from memory again
+
+
 def _full_size_grid(n, source, t=10):
     g = fdtd.Grid((n, n, n))
     for axis in range(3):
