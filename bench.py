@@ -270,6 +270,9 @@ def roofline(grid, cells, es, timing, mask, steps, workload):
         if rec:
             roof["traffic"] = rec.get("bytes_per_launch")
             roof["traffic_source"] = PMC_NOTE
+            if "shell" in rec:      # the half-step launches beside the marching kernel, both per step
+                roof["shell_traffic"] = rec["shell"]["bytes_per_step"]
+                roof["shell_cells"] = rec["shell"]["cells"]
     return roof
 
 
@@ -297,7 +300,7 @@ def measure_single(workload, steps, warmup, materials="auto"):
         "avg_launch_ms": roof["avg_launch_ms"], "achieved": roof["achieved"], "frac": roof["frac"],
         "materials": roof["materials"], "kernel": roof["kernel"],
         "bytes_per_launch": roof["bytes_per_launch"], "traffic": roof["traffic"],
-        **{k: roof[k] for k in ("kernel_cells", "shell_ms_per_step", "half_step_launches") if k in roof},
+        **{k: roof[k] for k in ("kernel_cells", "shell_ms_per_step", "half_step_launches", "shell_traffic") if k in roof},
     }
     del grid
     torch.cuda.empty_cache()
