@@ -185,7 +185,7 @@ def timed_run(grid, lib, _lib, steps, sync, events=True):
         grid.run(steps, progress_bar=False)
     sync()
     elapsed = time.perf_counter() - t0
-    ms, n = (ctypes.c_double * 4)(), (ctypes.c_int64 * 4)()
+    ms, n = (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
     _lib.check(lib.fdtdhip_plan_get_timing_parts(plan, ms, n))
     _lib.check(lib.fdtdhip_plan_enable_timing(plan, 0))
     core, hole = (ctypes.c_int32 * 6)(), (ctypes.c_int32 * 6)()
@@ -193,7 +193,7 @@ def timed_run(grid, lib, _lib, steps, sync, events=True):
     _lib.check(lib.fdtdhip_plan_whole_step_kind(plan, staged, core, hole))
     whole = n[2] if taken0 is None or grid._world == 1 else grid.whole_steps_taken - taken0
     return elapsed, {"ms": list(ms), "n": list(n), "whole_steps": int(whole),
-                     "core": list(core), "hole": list(hole)}
+                     "core": list(core), "hole": list(hole)}      # ms[4], n[4]: two-step launches
 
 
 def use_material_arrays(grid, lib, _lib):
@@ -227,7 +227,21 @@ def roofline(grid, cells, es, timing, mask, steps, workload):
            3: "constants"}[mask]
     roof = {"bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 0.0,
             "traffic": None, "traffic_source": None}
-    if whole > 0:
+    if n[4] > 0 and 2 * n[4] >= steps - 3:
+        # two steps per launch: E and H read once and written once per TWO steps (12 values per
+        # cell and launch, plus the material arrays where they are read)
+        values = 12 * cells + (0 if mask & 1 else 3 * cells) + (0 if mask & 2 else 3 * cells)
+        per_launch = values * es
+        avg_ms = ms[4] / n[4]
+        roof.update({
+            "kernel": "two-step marching kernel (E and H advanced twice in one pass)",
+            "steps_per_launch": 2, "launches_per_step": round(n[4] / steps, 2),
+            "other_launches": n[0] + n[1] + n[2],
+            # the same duration priced at the one-step kernels' 12 values per cell and STEP:
+            # what a kernel that passes over memory once per step would have to sustain
+            "one_pass_per_step_equivalent_GBps": round(2 * per_launch / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
+        })
+    elif whole > 0:
         c, h = timing["core"], timing["hole"]
         core = (c[1] - c[0]) * (c[3] - c[2]) * (c[5] - c[4])
         hole = (h[1] - h[0]) * (h[3] - h[2]) * (h[5] - h[4])
@@ -265,7 +279,7 @@ def roofline(grid, cells, es, timing, mask, steps, workload):
                  "materials": mat, "bytes_per_launch": per_launch, "avg_launch_ms": round(avg_ms, 4)})
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
-        key = f"{workload}:{mat}" + (":whole-step" if whole > 0 else "")
+        key = f"{workload}:{mat}" + (":two-steps" if "steps_per_launch" in roof else ":whole-step" if whole > 0 else "")
         rec = json.load(open(pmc)).get(key)
         if rec:
             roof["traffic"] = rec.get("bytes_per_launch")
@@ -300,7 +314,8 @@ def measure_single(workload, steps, warmup, materials="auto"):
         "avg_launch_ms": roof["avg_launch_ms"], "achieved": roof["achieved"], "frac": roof["frac"],
         "materials": roof["materials"], "kernel": roof["kernel"],
         "bytes_per_launch": roof["bytes_per_launch"], "traffic": roof["traffic"],
-        **{k: roof[k] for k in ("kernel_cells", "shell_ms_per_step", "half_step_launches", "shell_traffic") if k in roof},
+        **{k: roof[k] for k in ("kernel_cells", "shell_ms_per_step", "half_step_launches", "shell_traffic", "steps_per_launch",
+                                   "one_pass_per_step_equivalent_GBps") if k in roof},
     }
     del grid
     torch.cuda.empty_cache()
@@ -515,8 +530,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
         return float(t.item())
 
-    # on several GPUs rank 0 first times ONE slab of the same workload on its own (the other
-    # ranks wait): the per-GPU rate the N-slab value divides by for a scaling efficiency
+    # on several GPUs rank 0 first times, on its own, a one-GPU grid of the per-GPU size of the
+    # same workload (the other ranks wait).  It is NOT one of the run's slabs: it carries the PMLs
+    # of all six faces and exchanges nothing, where a slab has at most one x face and one or two
+    # neighbours (tools/slab_step_cost.py times real slabs with their exchanges on one GPU)
     one_slab = None
     if world > 1:
         if rank == 0 and workload != "c1":
@@ -560,7 +577,9 @@ def main():
             "roofline": roof,
         }
         if one_slab is not None:
-            out["one_gpu_same_slab"] = one_slab
+            one_slab["note"] = ("a one-GPU grid of the per-GPU size with the PMLs of all six faces and no "
+                                "exchange; not one of this run's slabs")
+            out["one_gpu_grid_of_slab_size"] = one_slab
     del grid
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and default_run and not args.no_also:

@@ -459,6 +459,15 @@ int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
     // where the caller's tensors are; an odd last step runs as two half steps
     GUARD(p);
     if (p->poisoned) return fail(-5, kPoisoned);
+    // plans with nothing between their steps but source points: two steps per launch, in
+    // pairs of launches (first -> second buffers and back)
+    if (whole_pair_possible(p, kind))
+      for (; s + 3 < nsteps; s += 4)
+        for (int k = 0; k < 2; ++k)
+          if (const int rc = whole_pair_step(p, q0 + s + 2 * k)) {
+            if (p->step_flipped) p->poisoned = true;
+            return rc;
+          }
     for (; s + 1 < nsteps; s += 2) {
       if (int rc = capacity_check(p, 2)) return rc;
       for (int k = 0; k < 2; ++k) {
@@ -660,15 +669,15 @@ int fdtdhip_plan_enable_timing(fdtdhip_plan* p, int on) {
   GUARD(p);
   if (int rc = drain_timing(p)) return rc;
   p->timing = on != 0;
-  for (int n = 0; n < 4; ++n) { p->ms[n] = 0; p->launches[n] = 0; }
+  for (int n = 0; n < TIME_KINDS; ++n) { p->ms[n] = 0; p->launches[n] = 0; }
   return 0;
 }
 
-int fdtdhip_plan_get_timing_parts(fdtdhip_plan* p, double ms[4], int64_t launches[4]) {
+int fdtdhip_plan_get_timing_parts(fdtdhip_plan* p, double ms[5], int64_t launches[5]) {
   if (!p) return fail(-1, "null plan");
   GUARD(p);
   if (int rc = drain_timing(p)) return rc;
-  for (int n = 0; n < 4; ++n) {
+  for (int n = 0; n < TIME_KINDS; ++n) {
     if (ms) ms[n] = p->ms[n];
     if (launches) launches[n] = p->launches[n];
     p->ms[n] = 0;
@@ -679,12 +688,12 @@ int fdtdhip_plan_get_timing_parts(fdtdhip_plan* p, double ms[4], int64_t launche
 
 int fdtdhip_plan_get_timing(fdtdhip_plan* p, double* ms_E, int64_t* launches_E, double* ms_H,
                             int64_t* launches_H) {
-  double ms[4];
-  int64_t n[4];
+  double ms[TIME_KINDS];
+  int64_t n[TIME_KINDS];
   if (int rc = fdtdhip_plan_get_timing_parts(p, ms, n)) return rc;
   // whole-step kernels and their shell launches are reported with the E half step
-  if (ms_E) *ms_E = ms[TIME_E] + ms[TIME_WHOLE] + ms[TIME_SHELL];
-  if (launches_E) *launches_E = n[TIME_E] + n[TIME_WHOLE];
+  if (ms_E) *ms_E = ms[TIME_E] + ms[TIME_WHOLE] + ms[TIME_SHELL] + ms[TIME_PAIR];
+  if (launches_E) *launches_E = n[TIME_E] + n[TIME_WHOLE] + n[TIME_PAIR];
   if (ms_H) *ms_H = ms[TIME_H];
   if (launches_H) *launches_H = n[TIME_H];
   return 0;

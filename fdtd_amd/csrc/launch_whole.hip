@@ -5,6 +5,7 @@
 #include "yee_generic.hpp"
 #include "yee_step.hpp"
 #include "yee_march.hpp"
+#include "yee_march2.hpp"
 #include "yee_shell.hpp"
 
 namespace fdtdhip {
@@ -21,6 +22,12 @@ constexpr int64_t FUSED_AUTO_MAX_CELLS = 1 << 17;
 #endif
 #ifndef FDTDHIP_MARCH_TY64
 #define FDTDHIP_MARCH_TY64 4   // the same in float64
+#endif
+#ifndef FDTDHIP_MARCH2_TY32
+#define FDTDHIP_MARCH2_TY32 4  // rows per wave of the two-step marching kernel in float32
+#endif
+#ifndef FDTDHIP_MARCH2_TY64
+#define FDTDHIP_MARCH2_TY64 3  // the same in float64 (4: spills)
 #endif
 constexpr int64_t MARCH_SHELL_SHARE = 6;   // shell cells at most a sixth of the grid
 
@@ -173,10 +180,10 @@ int march_slots(fdtdhip_plan* p, const void* kernel, int threads) {
 // chunk of planes; all of them should keep the machine busy in whole rounds: 960 workgroups on
 // 768 places (256^3 float64 with six faces) left three quarters of the CUs idle for a fifth of
 // the launch (340 -> 323 us).  Among the chunk lengths of 16 to 128 planes the one with the
-// fullest rounds wins, counting the plane every chunk evaluates past its end, and a single
-// round counting 3 % less than several (512^3 float32: 4 chunks of 128 planes in one round
+// fullest rounds wins, counting the `extra` planes every chunk evaluates beyond its own (one
+// for the one-step kernels), and a single round counting 3 % less than several (512^3 float32: 4 chunks of 128 planes in one round
 // 1.215 ms, 8 chunks of 64 in two rounds 1.183).
-int march_chunk_planes(int planes, int tiles, int slots) {
+int march_chunk_planes(int planes, int tiles, int slots, int extra) {
   static const int forced_lx = [] {
     const char* e = getenv("FDTDHIP_MARCH_LX");
     return e ? atoi(e) : 0;
@@ -189,7 +196,7 @@ int march_chunk_planes(int planes, int tiles, int slots) {
     if (lx > 128) continue;
     const int64_t wgs = (int64_t)tiles * ((planes + lx - 1) / lx);
     const int64_t rounds = (wgs + slots - 1) / slots;
-    const double score = (double)wgs / (double)(rounds * slots) * lx / (lx + 1.0) * (rounds >= 2 ? 1.0 : 0.97);
+    const double score = (double)wgs / (double)(rounds * slots) * lx / (lx + (double)extra) * (rounds >= 2 ? 1.0 : 0.97);
     if (score > best + 1e-9) { best = score; best_lx = lx; }
   }
   return std::max(best_lx, 1);
@@ -489,6 +496,81 @@ int staged_step(fdtdhip_plan* p, int64_t q, int stage) {
 }
 
 }  // namespace
+
+namespace {
+
+// Two steps in one launch (yee_march2.hpp), from the current buffers into the second ones.
+template <typename T, int TY>
+int pair_step(fdtdhip_plan* p, int64_t q) {
+  March2Args<T> m;
+  m.E0 = (const T*)p->E; m.H0 = (const T*)p->H;
+  m.E1 = (T*)p->E_alt;   m.H1 = (T*)p->H_alt;
+  m.nx = p->nx; m.ny = p->ny; m.nz = p->nz;
+  // the products the one-step kernels form per cell, (Courant number x inverse material),
+  // rounded once in T here as there
+  BulkArgs<T> e, h;
+  fill_material<T>(p, true, e);
+  fill_material<T>(p, false, h);
+  if (!e.mat_const || !h.mat_const) return fail(-1, "internal: two steps per launch need constant materials");
+  const T sc = (T)p->sc;
+  for (int c = 0; c < 3; ++c) { m.ce[c] = sc * e.bg[c]; m.ch[c] = sc * h.bg[c]; }
+  m.nsrc = 0;
+  for (const SourceH& s : p->sources) {
+    const double w0 = waveform(s, q), w1 = waveform(s, q + 1);
+    for (int64_t i = 0; i < s.n; ++i) {
+      if (m.nsrc >= MAX_STEP_SOURCES) return fail(-1, "internal: too many source points for a whole step");
+      const int64_t cell = s.elem_host[i] / 3, plane = (int64_t)p->ny * p->nz;
+      m.src_i[m.nsrc] = (int)(cell / plane);
+      m.src_j[m.nsrc] = (int)((cell % plane) / p->nz);
+      m.src_k[m.nsrc] = (int)(cell % p->nz);
+      m.src_c[m.nsrc] = (int)(s.elem_host[i] % 3);
+      m.src_v[0][m.nsrc] = (T)(s.profile_host[i] * w0);
+      m.src_v[1][m.nsrc] = (T)(s.profile_host[i] * w1);
+      ++m.nsrc;
+    }
+  }
+  for (int n = m.nsrc; n < MAX_STEP_SOURCES; ++n) {
+    m.src_i[n] = m.src_j[n] = m.src_k[n] = m.src_c[n] = -1;
+    m.src_v[0][n] = m.src_v[1][n] = T(0);
+  }
+  m.tiles = (p->ny + TY - 1) / TY;
+  m.nseg = (p->nz + MARCH2_ZOWN - 1) / MARCH2_ZOWN;
+  const int groups = (m.tiles * m.nseg + MARCH2_WAVES - 1) / MARCH2_WAVES;
+  void (*kernel)(March2Args<T>) = step_march2<T, TY>;
+  m.lx = march_chunk_planes(p->nx, groups, march_slots(p, (const void*)kernel, 64 * MARCH2_WAVES), 3);
+  m.band = groups >= 16 ? (groups + 7) / 8 : 0;
+  const dim3 grid(m.band ? 8 * m.band : groups, (p->nx + m.lx - 1) / m.lx, 1), block(64 * MARCH2_WAVES);
+  size_t slot;
+  if (int rc = span_begin(p, slot)) return rc;
+  hipLaunchKernelGGL(kernel, grid, block, 0, p->stream, m);
+  HIPCHK(hipGetLastError());
+  if (int rc = span_end(p, slot, TIME_PAIR)) return rc;
+  std::swap(p->E, p->E_alt);
+  std::swap(p->H, p->H_alt);
+  p->step_flipped = !p->step_flipped;
+  return 0;
+}
+
+}  // namespace
+
+// Whether runs of this plan may advance two steps per launch: a marching plan over the whole
+// grid, both materials constant, whose steps have nothing between them but additive source
+// points -- no detector to read, no curl trace to record (PMLs, objects and slab faces already
+// take the plan to the kernels with a shell; with material arrays to read twice the kernel
+// is slower than two one-step launches: 512^3 float32 2.26 against 1.81 ms per step).  FDTDHIP_MARCH2=0 in the environment: never (read at every call: tests compare
+// the two ways of stepping in one process).
+bool whole_pair_possible(const fdtdhip_plan* p, FusedKind kind) {
+  if (kind != FUSED_MARCH) return false;
+  const char* e = getenv("FDTDHIP_MARCH2");
+  if (e && atoi(e) == 0) return false;
+  return p->pmls.empty() && p->objs.empty() && !p->H_below && !p->E_above && p->dets.empty() &&
+         p->trace_cursor < 0 && p->nz >= MARCH2_ZOWN && p->mat_const[0] && p->mat_const[1] &&
+         (int64_t)p->ny * p->nz * 3 * (p->dtype == FDTDHIP_F32 ? 4 : 8) < (1ll << 32);   // in-plane byte offsets
+}
+
+int whole_pair_step(fdtdhip_plan* p, int64_t q) {
+  return DISPATCH(p, (pair_step<float, FDTDHIP_MARCH2_TY32>(p, q)), (pair_step<double, FDTDHIP_MARCH2_TY64>(p, q)));
+}
 
 int whole_fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {
   return DISPATCH(p, fused_step<float>(p, q, kind), fused_step<double>(p, q, kind));

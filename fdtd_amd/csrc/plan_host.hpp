@@ -203,8 +203,8 @@ struct fdtdhip_plan {
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   std::vector<int> ev_phase;  // what each used pair brackets (TIME_*)
-  double ms[4] = {0, 0, 0, 0};
-  int64_t launches[4] = {0, 0, 0, 0};
+  double ms[5] = {0, 0, 0, 0, 0};
+  int64_t launches[5] = {0, 0, 0, 0, 0};
   size_t esize() const { return dtype == FDTDHIP_F32 ? 4 : 8; }
   int64_t cells() const { return (int64_t)nx * ny * nz; }
 };
@@ -366,7 +366,7 @@ const Strategy& strategy();
 // What a pair of timing events brackets: a bulk half-step launch (H, E), a whole-step kernel
 // (step_march, step_march_box, step_fused), or the half-step launches over the shell that
 // accompany the marching kernel on plans with PMLs, objects or open slab faces.
-enum { TIME_H = 0, TIME_E = 1, TIME_WHOLE = 2, TIME_SHELL = 3 };
+enum { TIME_H = 0, TIME_E = 1, TIME_WHOLE = 2, TIME_SHELL = 3, TIME_PAIR = 4, TIME_KINDS = 5 };
 
 // The box of cells that no PML slab covers (slabs sit at the low or high end of their
 // axis) and the box that contains all objects.
@@ -440,9 +440,11 @@ int half_plane_energy(fdtdhip_plan* p, int axis, int index, void* outE, void* ou
 bool march_core(const fdtdhip_plan* p, int (&core)[6], int (&hole)[6]);
 FusedKind fused_kind(const fdtdhip_plan* p, bool staged = false);
 int whole_fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind);
+bool whole_pair_possible(const fdtdhip_plan* p, FusedKind kind);   // two steps per launch (yee_march2.hpp)
+int whole_pair_step(fdtdhip_plan* p, int64_t q);
 int whole_staged_step(fdtdhip_plan* p, int64_t q, int stage);
 int march_slots(fdtdhip_plan* p, const void* kernel, int threads);
-int march_chunk_planes(int planes, int tiles, int slots);
+int march_chunk_planes(int planes, int tiles, int slots, int extra = 1);
 
 // ---- launch_adjoint.hip -----------------------------------------------------------
 int adj_run(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH, void* work);

@@ -461,9 +461,11 @@ int fdtdhip_plan_get_timing(fdtdhip_plan* plan, double* ms_E, int64_t* launches_
                             double* ms_H, int64_t* launches_H);
 /* The same, by kind of launch: [0] H bulk kernels, [1] E bulk kernels, [2] whole-step kernels
  * (one launch advances E and H), [3] the half-step launches over the cells next to PMLs,
- * objects and open slab faces that accompany a whole-step kernel.  fdtdhip_plan_get_timing
- * reports [1] + [2] + [3] as the E time and [1] + [2] as the E launches. */
-int fdtdhip_plan_get_timing_parts(fdtdhip_plan* plan, double ms[4], int64_t launches[4]);
+ * objects and open slab faces that accompany a whole-step kernel, [4] launches that advance E
+ * and H by TWO steps (plans with nothing between their steps but additive source points).
+ * fdtdhip_plan_get_timing reports [1] + [2] + [3] + [4] as the E time and [1] + [2] + [4] as
+ * the E launches. */
+int fdtdhip_plan_get_timing_parts(fdtdhip_plan* plan, double ms[5], int64_t launches[5]);
 
 /* Stand-alone curls (reference fdtd/grid.py:29-76): out = curl(in), both device
  * (nx,ny,nz,3) arrays of `dtype`; enqueued on `stream`. */

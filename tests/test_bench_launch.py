@@ -30,7 +30,7 @@ def test_bench_starts_its_own_ranks():
     assert "gloo" in out["config"]["transport"]
     assert out["config"]["halo"].startswith("1024x1024x2")
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
-    assert out["one_gpu_same_slab"]["name"] == "m4"
+    assert out["one_gpu_grid_of_slab_size"]["name"] == "m4"
 
 
 def test_bench_help_needs_no_gpu():

@@ -239,7 +239,9 @@ def _long_oracle(shape, steps, dtype=np.float64):
         o.add_point_source((24, 22, 21), period=19)
         od = o.add_line_detector(list(range(8, 40)), [24] * 32, [23] * 32)
         oc = o.add_current_detector([23], [21], [22])
-        o.run(steps)
+        o.run(steps // 2)
+        o.midway = (o.E.copy(), o.H.copy())       # the fields after half of the steps
+        o.run(steps - steps // 2)
         _LONG[key] = (o, od, oc)
     return _LONG[key]
 
@@ -260,7 +262,10 @@ def test_thousand_steps_against_the_oracle(dtype):
     float64: relative L2 <= 1e-12 on the final fields and the whole detector records.
     float32: rounding errors accumulate over 1000 steps: the oracle's own float32 twin
     (same arithmetic on float32 arrays) ends 4e-5 from the float64 run.  The engine is
-    held to 1e-5 against that twin, and to 1e-4 against float64."""
+    held to 1e-5 against that twin, and to 1e-4 against float64.  The float64 run is met
+    within 1e-5 for the first 500 steps (the twin leaves that band between steps 550 and
+    600 on this scene, tools/fp32_horizon.py; a vacuum grid stays inside it for all 1000):
+    asserted on the fields after 500 steps."""
     fdtd.set_backend(f"hip.{dtype}")
     shape, steps = (48, 46, 44), 1000
     o, od, oc = _long_oracle(shape, steps)
@@ -280,7 +285,13 @@ def test_thousand_steps_against_the_oracle(dtype):
     det, cur = fdtd.LineDetector(), fdtd.CurrentDetector()
     g[8:40, 24, 23] = det
     g[23, 21, 22] = cur
-    g.run(steps, progress_bar=False)
+    if dtype == "float32":
+        g.run(steps // 2, progress_bar=False)
+        for name, got, want in (("E", host(g.E), o.midway[0]), ("H", host(g.H), o.midway[1])):
+            assert rel_l2(got, want) <= 1e-5, (name, "float32 engine against float64 after 500 steps")
+        g.run(steps - steps // 2, progress_bar=False)
+    else:
+        g.run(steps, progress_bar=False)
     torch.cuda.synchronize()
     assert g.time_steps_passed == steps
     assert np.isfinite(o.E).all() and np.abs(o.E).max() > 0

@@ -80,9 +80,13 @@ def _is_difference_quantity(name):
     return name.endswith("_I") or name.startswith("psi")
 
 
-def check_scene(seed, dtype, big=False, extras=False, substrate=False, crowded=False):
+def check_scene(seed, dtype, big=False, extras=False, substrate=False, crowded=False, inherent=False):
     """Returns (dict of quantities out of tolerance, scene), or None for a scene whose
-    oracle run is not finite."""
+    oracle run is not finite.  float32 fields must be within 1e-5 of the float32 twin and of the
+    float64 oracle.  Only for the scenes listed in FLOAT32_INHERENT (`inherent`) may the distance
+    to float64 be larger: up to 5e-5 if the twin is at least half as far from float64 itself, and
+    beyond that only where the engine reproduces the twin to 1e-6 (the deviation is then the
+    twin's own, digit for digit)."""
     fdtd.set_backend(f"hip.{dtype}")
     scene = (fuzz_scenes.random_substrate_scene(seed) if substrate
              else fuzz_scenes.random_scene(seed, big=big, extras=extras, crowded=crowded))
@@ -121,8 +125,9 @@ def check_scene(seed, dtype, big=False, extras=False, substrate=False, crowded=F
             continue
         if not to_twin <= 1e-5:
             bad[k] = dict(engine_twin=to_twin)
-        elif not (to_f64 <= 1e-5 or twin_to_f64 >= 0.5 * to_f64):
-            bad[k] = dict(engine_f64=to_f64, twin_f64=twin_to_f64)
+        elif not (to_f64 <= 1e-5 or (inherent and twin_to_f64 >= 0.5 * to_f64
+                                     and (to_f64 <= 5e-5 or to_twin <= 1e-6))):
+            bad[k] = dict(engine_f64=to_f64, twin_f64=twin_to_f64, engine_twin=to_twin)
     return bad, scene
 
 
@@ -135,7 +140,7 @@ FLOAT32_INHERENT = ((236, {}), (552, {}), (3084, dict(extras=True, crowded=True)
 def test_float32_scenes_far_from_float64_are_the_twins_rounding_not_the_kernels():
     bad = {}
     for seed, kw in FLOAT32_INHERENT:
-        out = check_scene(seed, "float32", **kw)
+        out = check_scene(seed, "float32", inherent=True, **kw)
         if out and out[0]:
             bad[seed] = out
     assert not bad, f"float32 engine differs from the float32 twin: {bad}"

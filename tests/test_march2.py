@@ -1,0 +1,126 @@
+"""Two steps per launch (csrc/yee_march2.hpp) against explicit half steps and the oracle.
+
+A large 3-D grid with nothing between its steps but additive point sources -- no PML, object,
+detector or recorded curl, materials the scan proves constant -- is advanced two steps per pass over memory: the state after the
+first of them exists in registers only.  Same sums on the same operands: the fields must equal
+those of explicit half steps (reference fdtd/grid.py:267-295) bit for bit, and the oracle's within
+the engine's tolerances.  Extents that are no multiples of the tile height (4 rows, float64: 2),
+of the 61 cells of a z row a wave owns or of the chunk length; sources on the corners of the
+grid, on both sides of a wave's first and last owned cells and of a chunk's first plane;
+numbers of steps that leave 0 to 3 steps to the one-step kernels and half steps; random start
+fields; with material arrays the one-step kernels must run instead.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fdtd_amd as fdtd
+from fdtd_amd import _lib
+from oracle import yee_numpy as orc
+from test_hip_parity import TOL, host, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+_CASES = [("float32", (70, 66, 1000), 9, False), ("float32", (131, 130, 260), 8, False),
+          ("float64", (67, 129, 500), 11, False), ("float32", (64, 128, 512), 6, True),
+          ("float64", (64, 70, 940), 4, True), ("float32", (150, 120, 244), 8, False),
+          ("float32", (160, 150, 183), 5, False)]
+
+
+def _pair_launches(grid, lib):
+    ms, n = (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
+    _lib.check(lib.fdtdhip_plan_get_timing_parts(grid._plan, ms, n))
+    return int(n[4]), int(n[2]), int(n[0])
+
+
+@pytest.mark.parametrize("dtype,shape,steps,dense", _CASES,
+                         ids=[f"{d}-{'x'.join(map(str, s))}-{n}{'-arrays' if a else ''}" for d, s, n, a in _CASES])
+def test_two_steps_per_launch_equal_half_steps_bitwise(dtype, shape, steps, dense):
+    fdtd.set_backend(f"hip.{dtype}")
+    nx, ny, nz = shape
+    rs = np.random.RandomState(31)
+    E0, H0 = 1e-2 * rs.randn(*shape, 3), 1e-2 * rs.randn(*shape, 3)
+    ie = 1.0 / (1 + rs.rand(*shape, 3)) if dense else None
+    im = 1.0 / (1 + rs.rand(*shape, 3)) if dense else None
+    zs = min(nz - 1, 122)
+    sources = (((nx // 2, ny // 2, nz // 2), 11), ((0, 0, 0), 7), ((nx - 1, ny - 1, nz - 1), 9),
+               ((33, 4, 60 % nz), 13), ((33, 3, 61 % nz), 5), ((min(nx - 1, 64), ny - 2, zs), 6),
+               ((min(nx - 1, 63), 1, zs - 1), 8))
+
+    def build():
+        g = fdtd.Grid(shape)
+        g.E, g.H = fdtd.backend.array(E0), fdtd.backend.array(H0)
+        if dense:
+            g.inverse_permittivity = fdtd.backend.array(ie)
+            g.inverse_permeability = fdtd.backend.array(im)
+        for cell, period in sources:
+            g[cell] = fdtd.PointSource(period=period)
+        return g
+
+    a = build()
+    a._provide_step_buffers()
+    lib = a._ensure_plan()
+    _lib.check(lib.fdtdhip_plan_enable_timing(a._plan, 1))
+    a.run(steps, progress_bar=False)
+    pairs, singles, halves = _pair_launches(a, lib)
+    _lib.check(lib.fdtdhip_plan_enable_timing(a._plan, 0))
+    if dense:   # material arrays would have to be read twice per launch: one step per launch
+        assert pairs == 0 and singles == 2 * (steps // 2) and halves == steps % 2
+    else:
+        assert pairs == 2 * (steps // 4), "the two-step kernel did not run"
+        assert singles == 2 * ((steps % 4) // 2) and halves == steps % 2
+    b = build()
+    for _ in range(steps):
+        b.update_E()
+        b.update_H()
+        b.time_steps_passed += 1
+    torch.cuda.synchronize()
+    assert float(a.E.abs().max()) > 0
+    assert torch.equal(a.E, b.E) and torch.equal(a.H, b.H)
+    # the one-step kernels with the switch off: the same bits again
+    os.environ["FDTDHIP_MARCH2"] = "0"
+    try:
+        c = build()
+        c._provide_step_buffers()
+        c._ensure_plan()
+        _lib.check(lib.fdtdhip_plan_enable_timing(c._plan, 1))
+        c.run(steps, progress_bar=False)
+        assert _pair_launches(c, lib)[0] == 0
+        _lib.check(lib.fdtdhip_plan_enable_timing(c._plan, 0))
+    finally:
+        del os.environ["FDTDHIP_MARCH2"]
+    assert torch.equal(a.E, c.E) and torch.equal(a.H, c.H)
+    if nx * ny * nz > 5_000_000:
+        return      # (the oracle comparison of the other shapes covers the arithmetic)
+    o = orc.OracleGrid(shape)
+    o.E[...], o.H[...] = E0, H0
+    if dense:
+        o.inverse_permittivity[...] = ie
+        o.inverse_permeability[...] = im
+    for cell, period in sources:
+        o.add_point_source(cell, period=period)
+    o.run(steps)
+    assert rel_l2(host(a.E), o.E) <= TOL[dtype] and rel_l2(host(a.H), o.H) <= TOL[dtype]
+
+
+def test_detectors_and_recorded_runs_keep_one_step_per_launch():
+    """A detector has to read every step's fields, a recorded run every step's curl: such plans
+    stay with the one-step kernels."""
+    fdtd.set_backend("hip.float32")
+    shape = (64, 128, 512)
+    g = fdtd.Grid(shape)
+    g[32, 64, 256] = fdtd.PointSource(period=9)
+    det = fdtd.LineDetector()
+    g[10:50, 64, 200] = det
+    g._provide_step_buffers()
+    lib = g._ensure_plan()
+    _lib.check(lib.fdtdhip_plan_enable_timing(g._plan, 1))
+    g.run(8, progress_bar=False)
+    pairs, singles, _ = _pair_launches(g, lib)
+    _lib.check(lib.fdtdhip_plan_enable_timing(g._plan, 0))
+    assert pairs == 0 and singles == 8
+    assert len(det.E) == 8
