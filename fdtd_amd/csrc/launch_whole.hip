@@ -26,6 +26,17 @@ constexpr int64_t FUSED_AUTO_MAX_CELLS = 1 << 17;
 #ifndef FDTDHIP_MARCH2_TY32
 #define FDTDHIP_MARCH2_TY32 4  // rows per wave of the two-step marching kernel in float32
 #endif
+// Rows per tile of the two-step kernels (MI355X, 512^3 vacuum, ms per launch of two steps).
+// A workgroup per tile (z rows of up to 512 cells), float32: 2 / 3 / 4 / 5 / 6 / 7 / 8 rows
+// 1.55 / 1.68 / 1.57 / 1.48 / 1.47 / 2.22 (spills) / 3.27; float64: 1 / 2 / 3 rows 4.96 / 3.23 /
+// 5.80 (spills).  Independent waves, float32: 2 / 3 / 4 / 6 / 8 rows 1.82 / 1.68 / 1.63 / 1.64 /
+// 2.13; float64: 2 / 3 rows 3.71 / 3.58, 4 spill.
+#ifndef FDTDHIP_MARCH2_ROWS_TY32
+#define FDTDHIP_MARCH2_ROWS_TY32 6   // rows per workgroup of the two-step kernel with a workgroup per tile
+#endif
+#ifndef FDTDHIP_MARCH2_ROWS_TY64
+#define FDTDHIP_MARCH2_ROWS_TY64 2
+#endif
 #ifndef FDTDHIP_MARCH2_TY64
 #define FDTDHIP_MARCH2_TY64 3  // the same in float64 (4: spills)
 #endif
@@ -500,7 +511,7 @@ int staged_step(fdtdhip_plan* p, int64_t q, int stage) {
 namespace {
 
 // Two steps in one launch (yee_march2.hpp), from the current buffers into the second ones.
-template <typename T, int TY>
+template <typename T, int TY, int TYR>
 int pair_step(fdtdhip_plan* p, int64_t q) {
   March2Args<T> m;
   m.E0 = (const T*)p->E; m.H0 = (const T*)p->H;
@@ -533,13 +544,32 @@ int pair_step(fdtdhip_plan* p, int64_t q) {
     m.src_i[n] = m.src_j[n] = m.src_k[n] = m.src_c[n] = -1;
     m.src_v[0][n] = m.src_v[1][n] = T(0);
   }
-  m.tiles = (p->ny + TY - 1) / TY;
-  m.nseg = (p->nz + MARCH2_ZOWN - 1) / MARCH2_ZOWN;
-  const int groups = (m.tiles * m.nseg + MARCH2_WAVES - 1) / MARCH2_WAVES;
-  void (*kernel)(March2Args<T>) = step_march2<T, TY>;
-  m.lx = march_chunk_planes(p->nx, groups, march_slots(p, (const void*)kernel, 64 * MARCH2_WAVES), 3);
+  // z rows of up to 512 cells: a workgroup of up to eight waves per tile, which hand each other
+  // what crosses their ends through LDS (step_march2_rows); longer rows: independent waves
+  // (step_march2).  FDTDHIP_MARCH2_ROWS=0 in the environment: independent waves always (tests).
+  const int waves = (p->nz + 63) / 64;
+  const char* env = getenv("FDTDHIP_MARCH2_ROWS");
+  const bool rows = waves <= MARCH2_ROW_WAVES && !(env && atoi(env) == 0);
+  void (*kernel)(March2Args<T>);
+  int groups, threads, extra;
+  if (rows) {
+    m.tiles = (p->ny + TYR - 1) / TYR;
+    m.nseg = waves;
+    groups = m.tiles;
+    threads = 64 * waves;
+    extra = 4;
+    kernel = step_march2_rows<T, TYR>;
+  } else {
+    m.tiles = (p->ny + TY - 1) / TY;
+    m.nseg = (p->nz + MARCH2_ZOWN - 1) / MARCH2_ZOWN;
+    groups = (m.tiles * m.nseg + MARCH2_WAVES - 1) / MARCH2_WAVES;
+    threads = 64 * MARCH2_WAVES;
+    extra = 3;
+    kernel = step_march2<T, TY>;
+  }
+  m.lx = march_chunk_planes(p->nx, groups, march_slots(p, (const void*)kernel, threads), extra);
   m.band = groups >= 16 ? (groups + 7) / 8 : 0;
-  const dim3 grid(m.band ? 8 * m.band : groups, (p->nx + m.lx - 1) / m.lx, 1), block(64 * MARCH2_WAVES);
+  const dim3 grid(m.band ? 8 * m.band : groups, (p->nx + m.lx - 1) / m.lx, 1), block(threads);
   size_t slot;
   if (int rc = span_begin(p, slot)) return rc;
   hipLaunchKernelGGL(kernel, grid, block, 0, p->stream, m);
@@ -569,7 +599,8 @@ bool whole_pair_possible(const fdtdhip_plan* p, FusedKind kind) {
 }
 
 int whole_pair_step(fdtdhip_plan* p, int64_t q) {
-  return DISPATCH(p, (pair_step<float, FDTDHIP_MARCH2_TY32>(p, q)), (pair_step<double, FDTDHIP_MARCH2_TY64>(p, q)));
+  return DISPATCH(p, (pair_step<float, FDTDHIP_MARCH2_TY32, FDTDHIP_MARCH2_ROWS_TY32>(p, q)),
+                  (pair_step<double, FDTDHIP_MARCH2_TY64, FDTDHIP_MARCH2_ROWS_TY64>(p, q)));
 }
 
 int whole_fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {

@@ -300,4 +300,265 @@ __global__ __launch_bounds__(64 * MARCH2_WAVES) __attribute__((amdgpu_waves_per_
   }
 }
 
+
+// ---- z rows of up to 512 cells: a workgroup per tile, every lane owns its cell -------------
+//
+// The independent waves above pay for their independence in memory requests: their windows of 61
+// cells start at no cache line, so a row segment of 732 B touches seven 128-byte lines instead of
+// six, the segments two waves store share a line, and a row of 512 cells takes nine waves (512^3
+// float32: 1.68 ms per launch; with the stores left out 1.07 ms, with windows of 64 owned cells --
+// wrong results, the cost of the addresses alone -- 1.30 ms).  Where all waves of a z row fit one
+// workgroup (eight waves, each lane with up to 256 registers) they hand each other the three
+// values per row and step that cross a wave's ends through LDS instead, at one barrier per plane:
+// the stages are one more plane apart, so that what a stage needs from the neighbouring wave was
+// written before the previous barrier,
+//       E' of plane i,  H' of plane i-1,  E'' of plane i-2,  H'' of plane i-3,
+// at the price of one more plane of E' and of H' carried in registers and a fourth plane of
+// redundant evaluation per chunk.
+
+constexpr int MARCH2_ROW_WAVES = 8;
+
+__device__ __forceinline__ float wave_above(float v) {      // lane l receives lane l + 1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_below(float v) {      // lane l receives lane l - 1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double wave_above(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_below(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// What crosses the ends of the waves, per parity of the plane: components x and y of each row.
+// Slot v holds what wave v - 1's last lane and wave v's first lane wrote.
+template <typename T, int TY>
+struct March2Exchange {
+  T e1[2][MARCH2_ROW_WAVES + 1][TY + 4][2];   // E' of the first lanes (for the last lane of the wave before)
+  T h1[2][MARCH2_ROW_WAVES + 1][TY + 4][2];   // H' of the last lanes (for the first lane of the wave after)
+  T e2[2][MARCH2_ROW_WAVES + 1][TY + 4][2];   // E'' of the first lanes
+};
+
+template <typename T, int TY, bool EDGE>
+__device__ __forceinline__ void march2_row_plane(const March2Args<T>& a, const March2Wave<T, TY + 4>& w,
+                                                 March2Exchange<T, TY>& x, int wave, int lane, int i,
+                                                 T (&Hp)[TY + 4][3], T (&E1a)[TY + 4][3], T (&E1b)[TY + 4][3],
+                                                 T (&H1a)[TY + 4][3], T (&H1b)[TY + 4][3], T (&E2a)[TY + 4][3]) {
+  constexpr int NR = TY + 4;
+  const int nx = a.nx, ny = a.ny;
+  T Hc[NR][3], En[NR][3], H1c[NR][3], E2c[NR][3];
+  const bool plane = i < nx;
+  const bool first = lane == 0, last = lane == 63;
+  auto hasy = [&](int r) { return !EDGE || w.j0 - 2 + r > 0; };
+  auto hasy1 = [&](int r) { return !EDGE || w.j0 - 2 + r < ny - 1; };
+  auto inside = [&](int r) { return !EDGE || (w.j0 - 2 + r >= 0 && w.j0 - 2 + r < ny); };
+  // ---- E' of plane i ----------------------------------------------------------------------
+  // (requesting the loads of plane i+1 here, to travel while the other stages are evaluated:
+  // 512^3 float32 1.74 against 1.57 ms per launch -- the registers they occupy, not the wait
+  // for them, is what the kernel is short of)
+  {
+    const int64_t pbase = (int64_t)min(i, nx - 1) * w.sx;
+    const T* hp = a.H0 + pbase;
+    const T* ep = a.E0 + pbase;
+    T zx[NR], zy[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const T* h = at_bytes(hp + w.joff[r], w.koff);
+      Hc[r][0] = h[0]; Hc[r][1] = h[1]; Hc[r][2] = h[2];
+      if (r >= 1) {
+        const T* e = at_bytes(ep + w.joff[r], w.koff);
+        En[r][0] = e[0]; En[r][1] = e[1]; En[r][2] = e[2];
+        const T* z = at_bytes(hp + w.joff[r], w.zoff);
+        zx[r] = z[0]; zy[r] = z[1];
+      } else {
+        En[r][0] = En[r][1] = En[r][2] = T(0);
+      }
+    }
+    const bool hasx = i > 0;
+#pragma unroll
+    for (int r = 1; r < NR; ++r) {
+      const T x_y = hasx ? Hc[r][1] - Hp[r][1] : T(0);
+      const T x_z = hasx ? Hc[r][2] - Hp[r][2] : T(0);
+      const T y_x = hasy(r) ? Hc[r][0] - Hc[r - 1][0] : T(0);
+      const T y_z = hasy(r) ? Hc[r][2] - Hc[r - 1][2] : T(0);
+      const T z_x = w.hasz ? Hc[r][0] - zx[r] : T(0);
+      const T z_y = w.hasz ? Hc[r][1] - zy[r] : T(0);
+      En[r][0] += w.ce[0] * (y_z - z_y);
+      En[r][1] += w.ce[1] * (z_x - x_z);
+      En[r][2] += w.ce[2] * (x_y - y_x);
+    }
+    if (EDGE && a.nsrc > 0) march2_sources<T, 1, NR, NR>(a, 0, i, w.j0, w.k, En);
+    if (first) {
+#pragma unroll
+      for (int r = 1; r < TY + 3; ++r) { x.e1[i & 1][wave][r][0] = En[r][0]; x.e1[i & 1][wave][r][1] = En[r][1]; }
+    }
+  }
+  // ---- H' of plane i-1 ----------------------------------------------------------------------
+#pragma unroll
+  for (int r = 0; r < NR; ++r) { H1c[r][0] = H1c[r][1] = H1c[r][2] = T(0); }
+#pragma unroll
+  for (int r = 1; r < TY + 3; ++r) {
+    const T nx0 = x.e1[(i - 1) & 1][wave + 1][r][0], ny0 = x.e1[(i - 1) & 1][wave + 1][r][1];
+    const T sx0 = wave_above(E1a[r][0]), sy0 = wave_above(E1a[r][1]);
+    const T ax = last ? nx0 : sx0, ay = last ? ny0 : sy0;
+    const T x_y = plane ? En[r][1] - E1a[r][1] : T(0);
+    const T x_z = plane ? En[r][2] - E1a[r][2] : T(0);
+    const T y_x = hasy1(r) ? E1a[r + 1][0] - E1a[r][0] : T(0);
+    const T y_z = hasy1(r) ? E1a[r + 1][2] - E1a[r][2] : T(0);
+    const T z_x = w.hasz1 ? ax - E1a[r][0] : T(0);
+    const T z_y = w.hasz1 ? ay - E1a[r][1] : T(0);
+    H1c[r][0] = Hp[r][0] - w.ch[0] * (y_z - z_y);
+    H1c[r][1] = Hp[r][1] - w.ch[1] * (z_x - x_z);
+    H1c[r][2] = Hp[r][2] - w.ch[2] * (x_y - y_x);
+  }
+  if (last) {
+#pragma unroll
+    for (int r = 2; r < TY + 3; ++r) { x.h1[(i - 1) & 1][wave + 1][r][0] = H1c[r][0]; x.h1[(i - 1) & 1][wave + 1][r][1] = H1c[r][1]; }
+  }
+  // ---- E'' of plane i-2 ---------------------------------------------------------------------
+  {
+    const int ie = i - 2;
+    const bool hasx = ie > 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { E2c[r][0] = E2c[r][1] = E2c[r][2] = T(0); }
+#pragma unroll
+    for (int r = 2; r < TY + 3; ++r) {
+      const T nx0 = x.h1[ie & 1][wave][r][0], ny0 = x.h1[ie & 1][wave][r][1];
+      const T sx0 = wave_below(H1a[r][0]), sy0 = wave_below(H1a[r][1]);
+      const T zx = first ? nx0 : sx0, zy = first ? ny0 : sy0;
+      const T x_y = hasx ? H1a[r][1] - H1b[r][1] : T(0);
+      const T x_z = hasx ? H1a[r][2] - H1b[r][2] : T(0);
+      const T y_x = hasy(r) ? H1a[r][0] - H1a[r - 1][0] : T(0);
+      const T y_z = hasy(r) ? H1a[r][2] - H1a[r - 1][2] : T(0);
+      const T z_x = w.hasz ? H1a[r][0] - zx : T(0);
+      const T z_y = w.hasz ? H1a[r][1] - zy : T(0);
+      E2c[r][0] = E1b[r][0] + w.ce[0] * (y_z - z_y);
+      E2c[r][1] = E1b[r][1] + w.ce[1] * (z_x - x_z);
+      E2c[r][2] = E1b[r][2] + w.ce[2] * (x_y - y_x);
+    }
+    if (EDGE && a.nsrc > 0) march2_sources<T, 2, TY + 3, NR>(a, 1, ie, w.j0, w.k, E2c);
+    if (first) {
+#pragma unroll
+      for (int r = 2; r < TY + 2; ++r) { x.e2[ie & 1][wave][r][0] = E2c[r][0]; x.e2[ie & 1][wave][r][1] = E2c[r][1]; }
+    }
+    if (ie >= w.i0 && ie < w.i1 && w.kown) {
+      T* ep = a.E1 + (int64_t)ie * w.sx;
+#pragma unroll
+      for (int r = 2; r < TY + 2; ++r) {
+        if (!inside(r)) continue;
+        T* o = at_bytes(ep + w.joff[r], w.koff);
+        march2_store(E2c[r][0], o);
+        march2_store(E2c[r][1], o + 1);
+        march2_store(E2c[r][2], o + 2);
+      }
+    }
+  }
+  // ---- H'' of plane i-3 ---------------------------------------------------------------------
+  {
+    const int ig = i - 3;
+    const bool plane2 = i - 2 < nx;     // E'' of plane i-2 exists
+    T h[NR][3];
+#pragma unroll
+    for (int r = 2; r < TY + 2; ++r) {
+      const T nx0 = x.e2[ig & 1][wave + 1][r][0], ny0 = x.e2[ig & 1][wave + 1][r][1];
+      const T sx0 = wave_above(E2a[r][0]), sy0 = wave_above(E2a[r][1]);
+      const T ax = last ? nx0 : sx0, ay = last ? ny0 : sy0;
+      const T x_y = plane2 ? E2c[r][1] - E2a[r][1] : T(0);
+      const T x_z = plane2 ? E2c[r][2] - E2a[r][2] : T(0);
+      const T y_x = hasy1(r) ? E2a[r + 1][0] - E2a[r][0] : T(0);
+      const T y_z = hasy1(r) ? E2a[r + 1][2] - E2a[r][2] : T(0);
+      const T z_x = w.hasz1 ? ax - E2a[r][0] : T(0);
+      const T z_y = w.hasz1 ? ay - E2a[r][1] : T(0);
+      h[r][0] = H1b[r][0] - w.ch[0] * (y_z - z_y);
+      h[r][1] = H1b[r][1] - w.ch[1] * (z_x - x_z);
+      h[r][2] = H1b[r][2] - w.ch[2] * (x_y - y_x);
+    }
+    if (ig >= w.i0 && ig < w.i1 && w.kown) {
+      T* hp = a.H1 + (int64_t)ig * w.sx;
+#pragma unroll
+      for (int r = 2; r < TY + 2; ++r) {
+        if (!inside(r)) continue;
+        T* o = at_bytes(hp + w.joff[r], w.koff);
+        march2_store(h[r][0], o);
+        march2_store(h[r][1], o + 1);
+        march2_store(h[r][2], o + 2);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      Hp[r][c] = Hc[r][c];
+      E1b[r][c] = E1a[r][c]; E1a[r][c] = En[r][c];
+      H1b[r][c] = H1a[r][c]; H1a[r][c] = H1c[r][c];
+      E2a[r][c] = E2c[r][c];
+    }
+  __syncthreads();
+}
+
+// Workgroup = the waves of the z rows of one tile (blockDim.x = 64 x waves <= 512), grid x = tiles
+// (in bands per XCD), grid y = chunks of planes.
+template <typename T, int TY>
+__global__ __launch_bounds__(64 * MARCH2_ROW_WAVES) void step_march2_rows(March2Args<T> a) {
+  constexpr int NR = TY + 4;
+  __shared__ March2Exchange<T, TY> x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = a.band > 0 ? (int)(blockIdx.x & 7) * a.band + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (tile >= a.tiles) return;       // (the whole workgroup)
+  const int nx = a.nx, ny = a.ny, nz = a.nz;
+  March2Wave<T, NR> w;
+  w.k = wave * 64 + lane;
+  w.kown = w.k < nz;
+  w.hasz = w.k > 0;
+  w.hasz1 = w.k < nz - 1;
+  w.j0 = tile * TY;
+  w.i0 = blockIdx.y * a.lx;
+  w.i1 = min(w.i0 + a.lx, nx);
+  const int is = max(w.i0 - 1, 0);
+  const unsigned sy = 3u * (unsigned)nz;
+  w.sx = (int64_t)sy * ny;
+  w.koff = 3u * (unsigned)sizeof(T) * (unsigned)min(w.k, nz - 1);
+  w.zoff = w.hasz ? w.koff - 3u * (unsigned)sizeof(T) : w.koff;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) w.joff[r] = (unsigned)min(max(w.j0 - 2 + r, 0), ny - 1) * sy;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { w.ce[c] = a.ce[c]; w.ch[c] = a.ch[c]; }
+  bool edge = w.j0 < 3 || w.j0 + TY + 2 >= ny;
+#pragma unroll
+  for (int n = 0; n < MAX_STEP_SOURCES; ++n)
+    edge |= n < a.nsrc && a.src_j[n] >= w.j0 - 2 && a.src_j[n] < w.j0 - 2 + NR &&
+            a.src_k[n] >= wave * 64 && a.src_k[n] < wave * 64 + 64;
+  T Hp[NR][3], E1a[NR][3], E1b[NR][3], H1a[NR][3], H1b[NR][3], E2a[NR][3];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      Hp[r][c] = T(0); E1a[r][c] = T(0); E1b[r][c] = T(0); H1a[r][c] = T(0); H1b[r][c] = T(0); E2a[r][c] = T(0);
+    }
+  if (is > 0) {
+    const T* hp = a.H0 + (int64_t)(is - 1) * w.sx;
+#pragma unroll
+    for (int r = 1; r < NR; ++r) {
+      const T* p = at_bytes(hp + w.joff[r], w.koff);
+      Hp[r][0] = p[0]; Hp[r][1] = p[1]; Hp[r][2] = p[2];
+    }
+  }
+  // (every wave of the workgroup takes the same number of planes, whichever version it runs:
+  // the barriers pair up)
+  const int iend = min(w.i1 + 2, nx + 2);
+  if (edge) {
+    for (int i = is; i <= iend; ++i) march2_row_plane<T, TY, true>(a, w, x, wave, lane, i, Hp, E1a, E1b, H1a, H1b, E2a);
+  } else {
+    for (int i = is; i <= iend; ++i) march2_row_plane<T, TY, false>(a, w, x, wave, lane, i, Hp, E1a, E1b, H1a, H1b, E2a);
+  }
+}
+
 }  // namespace fdtdhip

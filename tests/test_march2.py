@@ -4,7 +4,7 @@ A large 3-D grid with nothing between its steps but additive point sources -- no
 detector or recorded curl, materials the scan proves constant -- is advanced two steps per pass over memory: the state after the
 first of them exists in registers only.  Same sums on the same operands: the fields must equal
 those of explicit half steps (reference fdtd/grid.py:267-295) bit for bit, and the oracle's within
-the engine's tolerances.  Extents that are no multiples of the tile height (4 rows, float64: 2),
+the engine's tolerances.  Extents that are no multiples of the tile heights (6 or 4 rows, float64: 2 or 3),
 of the 61 cells of a z row a wave owns or of the chunk length; sources on the corners of the
 grid, on both sides of a wave's first and last owned cells and of a chunk's first plane;
 numbers of steps that leave 0 to 3 steps to the one-step kernels and half steps; random start
@@ -94,6 +94,16 @@ def test_two_steps_per_launch_equal_half_steps_bitwise(dtype, shape, steps, dens
     finally:
         del os.environ["FDTDHIP_MARCH2"]
     assert torch.equal(a.E, c.E) and torch.equal(a.H, c.H)
+    if nz <= 512 and not dense:
+        # rows of up to 512 cells take the kernel with a workgroup per tile; the kernel of
+        # independent waves (longer rows) on the same grid: the same bits once more
+        os.environ["FDTDHIP_MARCH2_ROWS"] = "0"
+        try:
+            d = build()
+            d.run(steps, progress_bar=False)
+        finally:
+            del os.environ["FDTDHIP_MARCH2_ROWS"]
+        assert torch.equal(a.E, d.E) and torch.equal(a.H, d.H)
     if nx * ny * nz > 5_000_000:
         return      # (the oracle comparison of the other shapes covers the arithmetic)
     o = orc.OracleGrid(shape)
