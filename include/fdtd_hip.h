@@ -257,7 +257,12 @@ int fdtdhip_update_H_post_stage(fdtdhip_plan* plan, int64_t q, int stage);
  * are provided and nothing has to happen between the half steps (no periodic
  * boundary, no plane source, no halo), fdtdhip_run advances pairs of steps with one
  * kernel per step, first -> second buffers and back; after the call the state is
- * in the first buffers again.  Contents of the second buffers are scratch. */
+ * in the first buffers again.  Contents of the second buffers are scratch.
+ * Large 3-D plans whose steps have nothing between them but additive source points
+ * (no PML, object, detector, recorded curl; both material arrays proven constant by
+ * fdtdhip_plan_scan_materials) advance TWO steps per kernel, in groups of four steps;
+ * the state after the odd steps of a group then never exists in memory.  The result
+ * is the one of the half steps either way, bit for bit. */
 int fdtdhip_plan_set_step_buffers(fdtdhip_plan* plan, void* E_alt, void* H_alt);
 int fdtdhip_plan_set_pml_step_buffer(fdtdhip_plan* plan, int id, void* psiE_alt);
 
