@@ -240,6 +240,13 @@ def roofline(grid, cells, es, timing, mask, steps, workload):
             # the same duration priced at the one-step kernels' 12 values per cell and STEP:
             # what a kernel that passes over memory once per step would have to sustain
             "one_pass_per_step_equivalent_GBps": round(2 * per_launch / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
+            # and at the single-sweep figure of 24 values per cell and step (every array read
+            # once per half step, what one sweep per half step has to move whatever the
+            # materials are): the rate that sets the 100 % mark of 8 TB/s / 96 B = 83.3 Gcells/s
+            # in float32 (41.7 in float64).  Two steps per pass move a quarter of it.
+            "all_arrays_equivalent_GBps": round(2 * cells * 24 * es / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
+            "single_sweep_roofline_Gcells_s": round(HBM_PEAK_GBPS / (24 * es), 1),
+            "vs_single_sweep_roofline": round(2 * cells / (avg_ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS / (24 * es)), 3) if avg_ms > 0 else 0.0,
         })
     elif whole > 0:
         c, h = timing["core"], timing["hole"]
