@@ -587,6 +587,11 @@ def main():
             one_slab["note"] = ("a one-GPU grid of the per-GPU size with the PMLs of all six faces and no "
                                 "exchange; not one of this run's slabs")
             out["one_gpu_grid_of_slab_size"] = one_slab
+            # the weak-scaling series of this workload starts at that grid, not at the one-GPU
+            # headline (512^3 vacuum, another workload and, with two steps per launch, another kernel)
+            out["scaling_note"] = ("weak-scaling series of '" + workload + "': its one-GPU point is "
+                                   "one_gpu_grid_of_slab_size.value here (= also." + workload + " of the "
+                                   "default one-GPU line); the one-GPU headline value belongs to another workload")
     del grid
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and default_run and not args.no_also:
