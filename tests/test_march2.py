@@ -134,3 +134,74 @@ def test_detectors_and_recorded_runs_keep_one_step_per_launch():
     _lib.check(lib.fdtdhip_plan_enable_timing(g._plan, 0))
     assert pairs == 0 and singles == 8
     assert len(det.E) == 8
+
+
+def _small_case(seed):
+    """A random small grid (extents of one cell, fewer rows than a tile, fewer planes than the
+    march looks ahead, z rows just long enough, just over 512 cells, ...) advanced two steps per
+    launch by both kernels: equal to explicit half steps bit for bit and to the oracle."""
+    rs = np.random.RandomState(seed)
+    dtype = ("float64", "float32")[seed % 2]
+    fdtd.set_backend(f"hip.{dtype}")
+    nx = int(rs.choice([1, 2, 3, 4, 5, 7, 20, 33]))
+    ny = int(rs.choice([1, 2, 3, 5, 6, 7, 13, 25]))
+    nz = int(rs.choice([61, 62, 64, 65, 122, 123, 130, 200, 512, 513, 600]))
+    shape, steps = (nx, ny, nz), int(rs.choice([4, 5, 8, 11]))
+    E0, H0 = 1e-2 * rs.randn(*shape, 3), 1e-2 * rs.randn(*shape, 3)
+    sources = [((int(rs.randint(nx)), int(rs.randint(ny)), int(rs.randint(nz))), int(rs.randint(5, 15)))
+               for _ in range(int(rs.randint(0, 4)))]
+    sources = list({c: p for c, p in sources}.items())      # (a repeated cell would be added serially)
+    eps = float(rs.choice([1.0, 1.7]))
+
+    def build():
+        g = fdtd.Grid(shape, permittivity=eps)
+        g.E, g.H = fdtd.backend.array(E0), fdtd.backend.array(H0)
+        for cell, period in sources:
+            g[cell] = fdtd.PointSource(period=period)
+        return g
+
+    a = build()
+    a._provide_step_buffers()
+    lib = a._ensure_plan()
+    _lib.check(lib.fdtdhip_plan_enable_timing(a._plan, 1))
+    a.run(steps, progress_bar=False)
+    pairs = _pair_launches(a, lib)[0]
+    _lib.check(lib.fdtdhip_plan_enable_timing(a._plan, 0))
+    assert pairs == 2 * (steps // 4), (shape, "the two-step kernel did not run")
+    b = build()
+    for _ in range(steps):
+        b.update_E()
+        b.update_H()
+        b.time_steps_passed += 1
+    os.environ["FDTDHIP_MARCH2_ROWS"] = "0"
+    try:
+        c = build()
+        c.run(steps, progress_bar=False)
+    finally:
+        del os.environ["FDTDHIP_MARCH2_ROWS"]
+    torch.cuda.synchronize()
+    assert torch.equal(a.E, b.E) and torch.equal(a.H, b.H), (seed, shape, steps, sources)
+    assert torch.equal(c.E, b.E) and torch.equal(c.H, b.H), (seed, shape, steps, sources, "independent waves")
+    o = orc.OracleGrid(shape, permittivity=eps)
+    o.E[...], o.H[...] = E0, H0
+    for cell, period in sources:
+        o.add_point_source(cell, period=period)
+    o.run(steps)
+    assert rel_l2(host(a.E), o.E) <= TOL[dtype] and rel_l2(host(a.H), o.H) <= TOL[dtype], (seed, shape)
+
+
+def test_two_steps_per_launch_on_random_small_grids():
+    """FDTDHIP_FUSED=2 gives grids of any size the marching kernels (read once per process,
+    hence the child)."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (f"import sys\nsys.path[:0] = [{os.path.dirname(here)!r}, {here!r}]\n"
+            "import test_march2 as t\n"
+            "for seed in range(120):\n"
+            "    t._small_case(seed)\n"
+            "print('two steps per launch on 120 small grids')\n")
+    done = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FDTDHIP_FUSED="2"),
+                          capture_output=True, text=True, timeout=280, cwd=here)
+    assert done.returncode == 0 and "two steps per launch" in done.stdout, done.stdout[-2000:] + done.stderr[-3000:]
