@@ -88,13 +88,31 @@ class _Run(torch.autograd.Function):
         # object tensors, (weight, bias) per modulated object, (P, osc, weight, bias) per source
         k = len(objs) + 2 * len(mods) + 4 * len(srcs)
         src_in = rest[len(objs) + 2 * len(mods):k]
-        # the run works on fresh state tensors; the inputs keep their values for autograd
-        grid.E, grid.H = E.detach().clone(), H.detach().clone()
+        # the run works on fresh state tensors; the inputs keep their values for autograd.
+        # A single step can be taken out of place instead of copying both fields first
+        # (fdtdhip_step_into: one launch from the input tensors into new ones) where the plan
+        # has a whole-step kernel for it -- the case of a run advanced one step per node
+        # (reference cortical/autoencoder.py:108-112).
         psis = [t.detach().clone() for t in rest[k:]]
         for n_p, p in enumerate(pmls):
             p._psiE, p._psiH = psis[2 * n_p], psis[2 * n_p + 1]
-        lib = grid._ensure_plan(steps=n)   # binds the fresh state tensors
+        into = None
+        if half is None and n == 1 and grid._single_steps_out_of_place():
+            grid.E, grid.H = E.detach(), H.detach()
+            if grid.E.is_contiguous() and grid.H.is_contiguous() and grid.E.dtype == bd.float == grid.H.dtype:
+                into = grid._step_buffers = (torch.empty_like(grid.E), torch.empty_like(grid.H))
+                for p in pmls:
+                    if getattr(p, "_psiE_alt", None) is None:
+                        p._psiE_alt = torch.empty_like(p._psiE)
+        if into is None:
+            grid.E, grid.H = E.detach().clone(), H.detach().clone()
+        lib = grid._ensure_plan(steps=n)   # binds the state tensors
         plan = grid._plan
+        if into is not None and _lib.check(lib.fdtdhip_plan_whole_step_kind(plan, 0, None, None)) == 0:
+            # no whole-step kernel for this plan after all: in place on copies
+            into = grid._step_buffers = None
+            grid.E, grid.H = grid.E.clone(), grid.H.clone()
+            lib = grid._ensure_plan(steps=n)
         traces, etraces = [], []
         for o in objs:
             tr = torch.empty((n, o.Nx * o.Ny * o.Nz, 3), dtype=bd.float, device=bd.device)   # every row is written
@@ -114,7 +132,16 @@ class _Run(torch.autograd.Function):
             src._recording = (*state, None, None, None, q0)
             src_state.append(state)
         try:
-            if half is None:
+            if into is not None:
+                kind = grid._native_run(lib, 1, into=True)
+                # the roles are exchanged: the new tensors hold the state
+                grid.E, grid.H = into
+                grid._step_buffers = None      # (the inputs: not ours to write to later)
+                if kind == 1:                  # psi_E went into the PMLs' second buffers
+                    for n_p, p in enumerate(pmls):
+                        p._psiE, p._psiE_alt = p._psiE_alt, None
+                        psis[2 * n_p] = p._psiE
+            elif half is None:
                 grid._native_run(lib, n)
             else:
                 grid._native_half_step(lib, half == "E")
@@ -144,6 +171,8 @@ class _Run(torch.autograd.Function):
         def start(g, shape):
             if g is None:
                 return bd.zeros(shape)
+            if g.dtype == bd.float:
+                return g.detach().clone(memory_format=torch.contiguous_format)
             return g.detach().to(dtype=bd.float).contiguous().clone()
 
         lamE, lamH = start(gE, full), start(gH, full)

@@ -228,9 +228,7 @@ class PML(Boundary):
             return ("pml-elsewhere", id(self))
         # (the memory-variable arrays themselves are not part of it: re-bound arrays are
         # handed to the plan by _native_refresh without rebuilding it)
-        alt = getattr(self, "_psiE_alt", None)
-        return ("pml", id(self), self.axis, self.side, self.thickness, tuple(self._psiE.shape),
-                alt.data_ptr() if alt is not None else 0)
+        return ("pml", id(self), self.axis, self.side, self.thickness, tuple(self._psiE.shape))
 
     def _native_refresh(self, lib, plan):
         """Before every run: the plan follows the arrays ``_psiE`` / ``_psiH`` are bound to."""
@@ -242,6 +240,14 @@ class PML(Boundary):
                 setattr(self, name, t.to(device=bd.device, dtype=bd.float).contiguous())
         _lib.check(lib.fdtdhip_plan_set_pml_state(plan, self._native_id, self._psiE.data_ptr(),
                                                    self._psiH.data_ptr()))
+        alt = getattr(self, "_psiE_alt", None)
+        if alt is not None and (alt.shape != self._psiE.shape or alt.dtype != self._psiE.dtype
+                                or alt.device != self._psiE.device):
+            alt = self._psiE_alt = None
+        if alt is not getattr(self, "_psiE_alt_bound", None):
+            _lib.check(lib.fdtdhip_plan_set_pml_step_buffer(
+                plan, self._native_id, alt.data_ptr() if alt is not None else None))
+            self._psiE_alt_bound = alt
 
     def _native_add(self, lib, plan):
         if not self._active:
@@ -261,6 +267,7 @@ class PML(Boundary):
             alt = self._psiE_alt = None
         if alt is not None:
             _lib.check(lib.fdtdhip_plan_set_pml_step_buffer(plan, self._native_id, alt.data_ptr()))
+        self._psiE_alt_bound = alt
 
     # ------------------------------------- the reference's attribute names
     def _expand(self, profile, pad_value):

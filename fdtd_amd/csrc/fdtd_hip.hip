@@ -489,6 +489,30 @@ int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
   return 0;
 }
 
+int fdtdhip_step_into(fdtdhip_plan* p, int64_t q) {
+  if (!p) return fail(-1, "null plan");
+  if (p->stage_next != 0) return fail(-1, kStaged);
+  GUARD(p);
+  if (p->poisoned) return fail(-5, kPoisoned);
+  if (p->step_flipped) return fail(-1, "internal: fdtdhip_step_into between the steps of a fused pair");
+  const FusedKind kind = fused_kind(p);
+  if (!kind) return fail(-1, "this plan cannot take a whole step in one pass (fdtdhip_plan_whole_step_kind)");
+  if (int rc = capacity_check(p, 1)) return rc;
+  if (const int rc = whole_fused_step(p, q, kind)) {
+    if (kind == FUSED_MARCH && !p->pmls.empty()) p->poisoned = true;   // memory variables advanced in place
+    else if (p->step_flipped) { std::swap(p->E, p->E_alt); std::swap(p->H, p->H_alt); p->step_flipped = false; }
+    return rc;
+  }
+  // the roles are exchanged: the step buffers hold the state, the former fields are the step
+  // buffers; the one-lane-per-cell kernel wrote psi_E of every PML into its step buffer too
+  // (the marching kernel's shell advances it in place)
+  if (kind != FUSED_MARCH)
+    for (PmlH& h : p->pmls) std::swap(h.psiE, h.psiE_alt);
+  p->pml_dirty = true;
+  p->step_flipped = false;
+  return (int)kind;
+}
+
 int fdtdhip_plan_whole_step_kind(fdtdhip_plan* p, int staged, int32_t core[6], int32_t hole[6]) {
   if (!p) return fail(-1, "null plan");
   const FusedKind kind = fused_kind(p, staged != 0);

@@ -23,7 +23,14 @@ def _is_int(v):
     return isinstance(v, (int, np.integer)) and not isinstance(v, bool)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_ptr(device):
+    """The current HIP stream of ``device`` (asked at every call: the caller may have
+    entered a ``torch.cuda.stream`` context)."""
+    if _raw_stream is not None and device.index is not None:
+        return ctypes.c_void_p(_raw_stream(device.index))   # (a tenth of the cost of the Stream object)
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
@@ -251,8 +258,15 @@ class Grid:
         backend precision if the user re-bound them to something else."""
         out = []
         full = (self.Nx, self.Ny, self.Nz, 3)
+        seen = getattr(self, "_fields_seen", {})
         for name in ("E", "H", "inverse_permittivity", "inverse_permeability"):
             t = getattr(self, name)
+            ok = seen.get(name)
+            # (a tensor found in order before keeps its shape, precision, device and layout
+            # unless the backend changed: one identity test instead of five properties)
+            if ok is not None and ok[0]() is t and ok[1] is bd.float and ok[2] == bd.device:
+                out.append(t)
+                continue
             if not torch.is_tensor(t):
                 t = bd.array(t)
             if tuple(t.shape) != full:
@@ -261,7 +275,9 @@ class Grid:
                 t = t.to(device=bd.device, dtype=bd.float).contiguous()
             if t is not getattr(self, name):
                 setattr(self, name, t)
+            seen[name] = (weakref.ref(t), bd.float, bd.device)
             out.append(t)
+        self._fields_seen = seen
         return out
 
     def _signature(self):
@@ -337,6 +353,7 @@ class Grid:
 
     _MAX_MATERIAL_SCANS = 4
     _MATERIAL_RECHECK_STEPS = 16
+    _MATERIAL_RECHECK_STEPS_SMALL = 256    # grids of fewer than 2**17 cells
 
     def _scan_materials(self, lib, ie, im, steps=1):
         """Let the library find out whether the material arrays are constant outside
@@ -351,7 +368,8 @@ class Grid:
         shorter calls (single steps, half steps) do so once that many steps have gone by
         since the last scan -- a scan reads both arrays once, half of what a step moves.  A
         run of 16 steps or more therefore never uses stale constants; hand-driven stepping
-        may for at most 15 steps, unless ``materials_changed()`` is called."""
+        may for at most 15 steps, unless ``materials_changed()`` is called (on grids of fewer
+        than 2**17 cells, whose step takes microseconds: for at most 255 steps)."""
         # (the tensors themselves are part of the key, held weakly: a re-bound array can land
         # on the address of the one it replaced, with the same version count)
         key = (ie.data_ptr(), ie._version, im.data_ptr(), im._version)
@@ -362,7 +380,11 @@ class Grid:
                     getattr(self, "_material_scans", 0) >= self._MAX_MATERIAL_SCANS:
                 return            # no constants in use: the kernels read the arrays
             gone = getattr(self, "_steps_since_scan", 0)
-            if steps < self._MATERIAL_RECHECK_STEPS and gone + steps <= self._MATERIAL_RECHECK_STEPS:
+            # (a scan ends in a read-back that waits for the stream, about 0.15 ms whatever the
+            # size: on grids whose step takes 10 us it is spread over more steps)
+            patience = self._MATERIAL_RECHECK_STEPS if self.Nx * self.Ny * self.Nz >= 1 << 17 \
+                else self._MATERIAL_RECHECK_STEPS_SMALL
+            if steps < self._MATERIAL_RECHECK_STEPS and gone + steps <= patience:
                 self._steps_since_scan = gone + steps
                 return
             self._materials_mask = _lib.check(lib.fdtdhip_plan_scan_materials(self._plan, 1))
@@ -507,16 +529,27 @@ class Grid:
         self._native_run(lib, n)
         self.time_steps_passed += n
 
-    def _native_run(self, lib, n):
+    def _native_run(self, lib, n, into=False):
         """``n`` full steps from ``time_steps_passed`` on the prepared plan (the counter is
-        advanced by the caller)."""
+        advanced by the caller).  ``into``: one step, out of place into the step buffers
+        (``fdtdhip_step_into``; returns the kind of whole-step kernel that took it)."""
         self._prepare_sources(lib, n)
         for det in self.detectors:
             det._reserve(lib, self._plan, n, n)
-        _lib.check(lib.fdtdhip_run(self._plan, self.time_steps_passed, n))
+        if into:
+            kind = _lib.check(lib.fdtdhip_step_into(self._plan, self.time_steps_passed))
+        else:
+            kind = _lib.check(lib.fdtdhip_run(self._plan, self.time_steps_passed, n))
         for det in self.detectors:
             det._commit(n, n)
         self._finish_sources(n)
+        return kind
+
+    def _single_steps_out_of_place(self):
+        """Whether a recorded single step may be taken out of place (a whole grid on one
+        device; slabs step in stages around their exchanges)."""
+        return (type(self)._native_run is Grid._native_run and self.Nx == self.Nx_global
+                and self._halo == (None, None))
 
     def _prepare_sources(self, lib, n):
         """Sources with per-run inputs hand them to the plan (steps time_steps_passed ...)."""

@@ -295,6 +295,18 @@ int fdtdhip_run(fdtdhip_plan* plan, int64_t q0, int64_t nsteps);
 int fdtdhip_plan_whole_step_kind(fdtdhip_plan* plan, int staged, int32_t core[6], int32_t hole[6]);
 int fdtdhip_step_stage(fdtdhip_plan* plan, int64_t q, int stage);
 
+/* One whole step OUT OF PLACE (no reference counterpart: the reference's torch backend gets
+ * new arrays from every operation it records, fdtd/grid.py:283-325 under autograd): reads the
+ * bound fields, writes the new E and H into the step buffers and leaves the bound fields as
+ * they were -- for callers that need the old state intact, such as a differentiable run
+ * advanced one step per autograd node, which would otherwise copy both fields first.
+ * Afterwards the roles are exchanged: the former step buffers are the plan's fields, the
+ * former fields its step buffers; with the one-lane-per-cell kernel (return value 1) likewise
+ * psi_E of every PML and its step buffer, while the marching kernel (2) and psi_H always
+ * advance the memory variables in place.  Fails, without stepping, if the plan cannot take a
+ * whole step in one pass (fdtdhip_plan_whole_step_kind returns 0). */
+int fdtdhip_step_into(fdtdhip_plan* plan, int64_t q);
+
 /* ---- differentiable runs (backward through time) ---------------------------
  * The reference differentiates through grid.run with torch autograd, recording
  * every slice operation of every step (reference examples/learnable_focus.py:98-128,

@@ -272,3 +272,59 @@ def test_large_plane_adjoint_against_finite_differences(absorbing):
         numeric = (loss_of(gp).item() - loss_of(gm).item()) / (2 * h)
     assert abs(analytic) > 0
     assert abs(analytic - numeric) <= 1e-6 * abs(numeric), (analytic, numeric)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_single_recorded_steps_are_taken_out_of_place(dtype):
+    """A recorded run advanced one step per autograd node (reference cortical/autoencoder.py:108-112)
+    takes each step in one launch from the node's input tensors into new ones
+    (fdtdhip_step_into) instead of copying the fields first: the inputs stay what they were,
+    fields and memory variables equal those of one node over all steps bit for bit, and so do
+    the gradients.  2-D grid with four PMLs (the one-lane-per-cell kernel: psi_E goes into new
+    arrays too), a learnable object, a source and a detector."""
+    fdtd.set_backend(f"hip.{dtype}")
+    rs = np.random.RandomState(12)
+    E0n, off = 1e-2 * rs.randn(60, 50, 1, 3), 0.05 * rs.randn(20, 14, 1, 3, 3)
+
+    def build():
+        g = fdtd.Grid((60, 50, 1))
+        g[0:6, :, :] = fdtd.PML()
+        g[-6:, :, :] = fdtd.PML()
+        g[:, 0:6, :] = fdtd.PML()
+        g[:, -6:, :] = fdtd.PML()
+        obj = fdtd.LearnableAnisotropicObject(permittivity=2.0)
+        g[20:40, 18:32, 0] = obj
+        with torch.no_grad():
+            obj.inverse_permittivity += fdtd.backend.array(off)
+        g[12, 25, 0] = fdtd.PointSource(period=9)
+        det = fdtd.LineDetector()
+        g[45, 10:40, 0] = det
+        E0 = fdtd.backend.array(E0n).requires_grad_(True)
+        g.E = E0
+        return g, obj, det, E0
+
+    steps = 9
+    a, obj_a, det_a, E0a = build()
+    a.run(steps, progress_bar=False)
+    b, obj_b, det_b, E0b = build()
+    held = []
+    for _ in range(steps):
+        before = b.E
+        snapshot = before.detach().clone()
+        b.run(1, progress_bar=False)
+        assert b.E is not before and torch.equal(before.detach(), snapshot)   # the input is left alone
+        held.append(b.E)
+    torch.cuda.synchronize()
+    assert b.time_steps_passed == steps
+    assert torch.equal(a.E, b.E) and torch.equal(a.H, b.H)
+    for pa, pb in zip(a.boundaries, b.boundaries):
+        assert torch.equal(pa._psiE, pb._psiE) and torch.equal(pa._psiH, pb._psiH)
+    assert torch.equal(torch.stack(list(det_a.E)), torch.stack(list(det_b.E)))
+    w = fdtd.backend.array(rs.randn(60, 50, 1, 3))
+    (w * a.E * a.E).sum().backward()
+    # (the loss of the stepwise run also reads the E of an earlier node: still there)
+    ((w * b.E * b.E).sum() + 0.0 * held[3].sum()).backward()
+    assert float(obj_a.inverse_permittivity.grad.abs().max()) > 0
+    tol = 1e-12 if dtype == "float64" else 1e-5
+    assert rel_l2(obj_b.inverse_permittivity.grad.cpu(), obj_a.inverse_permittivity.grad.cpu()) <= tol
+    assert rel_l2(E0b.grad.cpu(), E0a.grad.cpu()) <= tol

@@ -129,15 +129,20 @@ def test_material_write_that_torch_cannot_see_is_caught_by_the_next_long_run():
     o.inverse_permeability[4:9, 33:37, 30:34, 1] *= 0.9
     g.run(16, progress_bar=False); o.run(16)
     assert rel_l2(host(g.E), o.E) <= 1e-12 and rel_l2(host(g.H), o.H) <= 1e-12
-    # single steps: noticed once 16 of them have gone by since the last scan
-    h = fdtd.Grid(shape)
-    h[6, 35, 32] = fdtd.PointSource(period=9)
-    h.run(3, progress_bar=False)
-    assert h._materials_mask == 3
-    h.inverse_permittivity.data[5:8, 30:40, 28:36, :] = 0.4
-    for _ in range(17):
-        h.run(1, progress_bar=False)
-    assert h._materials_mask == 2      # the inverse permittivity is read from memory again
+    # single steps: noticed once 16 of them have gone by since the last scan (grids of fewer
+    # than 2**17 cells, whose scan costs as much as fifteen steps: once 256 have gone by)
+    for shape, patience in (((32, 70, 64), 16), (shape, 256)):
+        h = fdtd.Grid(shape)
+        h[6, 35, 32] = fdtd.PointSource(period=9)
+        h.run(3, progress_bar=False)
+        assert h._materials_mask == 3
+        h.inverse_permittivity.data[5:8, 30:40, 28:36, :] = 0.4
+        for _ in range(patience - 3):
+            h.run(1, progress_bar=False)
+        assert h._materials_mask == 3
+        for _ in range(2):
+            h.run(1, progress_bar=False)
+        assert h._materials_mask == 2      # the inverse permittivity is read from memory again
 
 
 def _full_size_grid(n, source, t=10):
