@@ -188,12 +188,14 @@ def timed_run(grid, lib, _lib, steps, sync, events=True):
     ms, n = (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
     _lib.check(lib.fdtdhip_plan_get_timing_parts(plan, ms, n))
     _lib.check(lib.fdtdhip_plan_enable_timing(plan, 0))
-    core, hole = (ctypes.c_int32 * 6)(), (ctypes.c_int32 * 6)()
+    core, hole, inner = (ctypes.c_int32 * 6)(), (ctypes.c_int32 * 6)(), (ctypes.c_int32 * 6)()
+    two_step = _lib.check(lib.fdtdhip_plan_two_step_box(plan, inner))
     staged = 1 if taken0 is not None and grid._world > 1 else 0
     _lib.check(lib.fdtdhip_plan_whole_step_kind(plan, staged, core, hole))
     whole = n[2] if taken0 is None or grid._world == 1 else grid.whole_steps_taken - taken0
     return elapsed, {"ms": list(ms), "n": list(n), "whole_steps": int(whole),
-                     "core": list(core), "hole": list(hole)}      # ms[4], n[4]: two-step launches
+                     "core": list(core), "hole": list(hole),      # ms[4], n[4]: two-step launches
+                     "inner": list(inner) if two_step else None}
 
 
 def use_material_arrays(grid, lib, _lib):
@@ -230,23 +232,29 @@ def roofline(grid, cells, es, timing, mask, steps, workload):
     if n[4] > 0 and 2 * n[4] >= steps - 3:
         # two steps per launch: E and H read once and written once per TWO steps (12 values per
         # cell and launch, plus the material arrays where they are read)
-        values = 12 * cells + (0 if mask & 1 else 3 * cells) + (0 if mask & 2 else 3 * cells)
-        per_launch = values * es
+        b = timing.get("inner") or [0, 0, 0, 0, 0, 0]
+        inner = (b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]) or cells
+        per_launch = 12 * inner * es      # (constant materials: the kernel's condition)
         avg_ms = ms[4] / n[4]
+        pass_ms = (ms[4] + ms[3]) / n[4]
         roof.update({
-            "kernel": "two-step marching kernel (E and H advanced twice in one pass)",
+            "kernel": ("two-step marching kernel (E and H advanced twice in one pass)" if inner == cells else
+                       "two-step marching kernel over the cells three or more away from PML faces; "
+                       "two steps of half-step launches over the others"),
+            "kernel_cells": inner, "grid_cells": cells,
+            "shell_ms_per_step": round(ms[3] / steps, 4),
             "steps_per_launch": 2, "launches_per_step": round(n[4] / steps, 2),
             "other_launches": n[0] + n[1] + n[2],
-            # the same duration priced at the one-step kernels' 12 values per cell and STEP:
-            # what a kernel that passes over memory once per step would have to sustain
-            "one_pass_per_step_equivalent_GBps": round(2 * per_launch / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
-            # and at the single-sweep figure of 24 values per cell and step (every array read
-            # once per half step, what one sweep per half step has to move whatever the
-            # materials are): the rate that sets the 100 % mark of 8 TB/s / 96 B = 83.3 Gcells/s
-            # in float32 (41.7 in float64).  Two steps per pass move a quarter of it.
-            "all_arrays_equivalent_GBps": round(2 * cells * 24 * es / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
+            # the time of a pass over the WHOLE grid (with a shell: its launches included)
+            # priced at the one-step kernels' 12 values per cell and STEP -- what a kernel that
+            # passes over memory once per step would have to sustain -- and at the single-sweep
+            # figure of 24 values per cell and step (every array read once per half step), the
+            # rate that sets the 100 % mark of 8 TB/s / 96 B = 83.3 Gcells/s in float32 (41.7 in
+            # float64).  Two steps per pass move a quarter of the latter.
+            "one_pass_per_step_equivalent_GBps": round(2 * cells * 12 * es / (pass_ms * 1e-3) / 1e9, 1) if pass_ms > 0 else 0.0,
+            "all_arrays_equivalent_GBps": round(2 * cells * 24 * es / (pass_ms * 1e-3) / 1e9, 1) if pass_ms > 0 else 0.0,
             "single_sweep_roofline_Gcells_s": round(HBM_PEAK_GBPS / (24 * es), 1),
-            "vs_single_sweep_roofline": round(2 * cells / (avg_ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS / (24 * es)), 3) if avg_ms > 0 else 0.0,
+            "vs_single_sweep_roofline": round(2 * cells / (pass_ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS / (24 * es)), 3) if pass_ms > 0 else 0.0,
         })
     elif whole > 0:
         c, h = timing["core"], timing["hole"]

@@ -454,21 +454,24 @@ int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
   if (!p) return fail(-1, "null plan");
   if (p->stage_next != 0) return fail(-1, kStaged);
   int64_t s = 0;
-  if (const FusedKind kind = fused_kind(p)) {
+  const FusedKind kind = fused_kind(p);
+  const bool pairs = nsteps >= 4 && whole_pair_possible(p);
+  if (kind || pairs) {
     // pairs of fused steps: first -> second buffers and back, so that the state ends
     // where the caller's tensors are; an odd last step runs as two half steps
     GUARD(p);
     if (p->poisoned) return fail(-5, kPoisoned);
-    // plans with nothing between their steps but source points: two steps per launch, in
-    // pairs of launches (first -> second buffers and back)
-    if (whole_pair_possible(p, kind))
+    // plans with nothing between their steps but source points: two steps per pass, in
+    // pairs of passes (first -> second buffers and back)
+    if (pairs)
       for (; s + 3 < nsteps; s += 4)
         for (int k = 0; k < 2; ++k)
           if (const int rc = whole_pair_step(p, q0 + s + 2 * k)) {
-            if (p->step_flipped) p->poisoned = true;
+            // (memory variables are advanced in place: a pass that stops half way cannot be repeated)
+            if (p->step_flipped || !p->pmls.empty()) p->poisoned = true;
             return rc;
           }
-    for (; s + 1 < nsteps; s += 2) {
+    for (; kind && s + 1 < nsteps; s += 2) {
       if (int rc = capacity_check(p, 2)) return rc;
       for (int k = 0; k < 2; ++k) {
         const int rc = whole_fused_step(p, q0 + s + k, kind);
@@ -524,6 +527,11 @@ int fdtdhip_plan_whole_step_kind(fdtdhip_plan* p, int staged, int32_t core[6], i
     if (hole) hole[n] = h[n];
   }
   return (int)kind;
+}
+
+int fdtdhip_plan_two_step_box(fdtdhip_plan* p, int32_t inner[6]) {
+  if (!p) return fail(-1, "null plan");
+  return whole_pair_possible(p, inner) ? 1 : 0;
 }
 
 int fdtdhip_step_stage(fdtdhip_plan* p, int64_t q, int stage) {

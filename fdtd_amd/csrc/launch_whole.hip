@@ -40,7 +40,6 @@ constexpr int64_t FUSED_AUTO_MAX_CELLS = 1 << 17;
 #ifndef FDTDHIP_MARCH2_TY64
 #define FDTDHIP_MARCH2_TY64 3  // the same in float64 (4: spills)
 #endif
-constexpr int64_t MARCH_SHELL_SHARE = 6;   // shell cells at most a sixth of the grid
 
 // Plans with PML faces take the marching step over the box no face reaches, with half steps
 // of their own for the shell around it (yee_shell.hpp).  That needs a box.
@@ -78,7 +77,7 @@ bool march_core(const fdtdhip_plan* p, int (&core)[6], int (&hole)[6]) {
 
 // `staged`: asked by fdtdhip_step_stage, the whole step in pieces around the halo exchanges
 // of an x-slab -- the marching step or nothing.
-FusedKind fused_kind(const fdtdhip_plan* p, bool staged) {
+FusedKind fused_kind(const fdtdhip_plan* p, bool staged, double shell_share) {
   // FDTDHIP_FUSED=0 never, =1 step_fused whenever possible, =2 step_march whenever possible
   // (tests).  By default step_fused only where it was measured faster than two half-step
   // launches (MI355X, PML on every face, tools/mid_cost.py): 2-D grids up to about 420 x 420
@@ -131,7 +130,7 @@ FusedKind fused_kind(const fdtdhip_plan* p, bool staged) {
   // (256^3 with six ten-cell faces, 22 % of the cells: float64 0.489 against 0.508 ms per step
   // in a bare loop and no difference in the benchmark, float32 0.256 against 0.235)
   if (march_ok && p->nz >= 128 && p->ny >= 64 && p->nx >= 64 && p->cells() >= (1ll << 22) &&
-      shell_cells * MARCH_SHELL_SHARE <= p->cells())
+      (double)shell_cells <= shell_share * (double)p->cells())
     return FUSED_MARCH;
   return FUSED_NONE;
 }
@@ -508,24 +507,96 @@ int staged_step(fdtdhip_plan* p, int64_t q, int stage) {
 
 }  // namespace
 
+// ---- two steps per pass (yee_march2.hpp) ------------------------------------------------
+// Whole grids without PML faces: one launch of the two-step kernel.  Plans with PML faces:
+// the two-step kernel advances the box `inner` = the PML-free core shrunk by two cells on every
+// side that has a shell (its cells and the two layers around them are plain, so it needs the
+// state before the pair and nothing else), and the cells outside `inner` take the two steps
+// one after the other with the shell kernels of the one-step march (yee_shell.hpp):
+//   1. two-step kernel over `inner`:            (E, H)(n) of A  ->  (E, H)(n+2) of B
+//   2. first step of the others, in place in A (nothing reads A's old values any more):
+//        E half step over the cells outside `inner` shrunk by two more cells,
+//        H half step over the cells outside `inner` shrunk by one
+//      (the extra layers belong to `inner`: their state after the first step, which the
+//      two-step kernel kept in registers, is what the second step of the cells next to `inner`
+//      reads; evaluated as the plain cells they are)
+//   3. second step of the cells outside `inner`, from A into B: E half step, then H half
+//      step, which reads the new E of `inner`'s outermost cells from B.
+// Same operations on the same operands as four half steps everywhere: bitwise equal.
+
+constexpr double MARCH2_OUTSIDE_SHARE = 0.4;   // cells outside the inner box: at most this share
+
 namespace {
 
-// Two steps in one launch (yee_march2.hpp), from the current buffers into the second ones.
+// The core box of a plan shrunk by `m` cells on every side where a shell lies (a side that
+// coincides with a face of the grid has none).  False if nothing is left.
+bool shrunk_core(const fdtdhip_plan* p, const int (&core)[6], int m, int (&box)[6]) {
+  const int n[3] = {p->nx, p->ny, p->nz};
+  for (int ax = 0; ax < 3; ++ax) {
+    box[2 * ax] = core[2 * ax] > 0 ? core[2 * ax] + m : 0;
+    box[2 * ax + 1] = core[2 * ax + 1] < n[ax] ? core[2 * ax + 1] - m : n[ax];
+    if (box[2 * ax + 1] - box[2 * ax] < 1) return false;
+  }
+  return true;
+}
+
+bool inside_box(const fdtdhip_plan* p, const int (&box)[6], int64_t elem) {
+  const int64_t plane = (int64_t)p->ny * p->nz, cell = elem / 3;
+  const int i = (int)(cell / plane), j = (int)((cell % plane) / p->nz), k = (int)(cell % p->nz);
+  return i >= box[0] && i < box[1] && j >= box[2] && j < box[3] && k >= box[4] && k < box[5];
+}
+
+// The cells outside `c` as disjoint boxes: x slabs over everything, y slabs between them, z
+// slabs inside.
+Shell shell_around(const fdtdhip_plan* p, const int (&c)[6]) {
+  const int nx = p->nx, ny = p->ny, nz = p->nz;
+  const ShellBox boxes[6] = {{0, c[0], 0, ny, 0, nz}, {c[1], nx, 0, ny, 0, nz},
+                             {c[0], c[1], 0, c[2], 0, nz}, {c[0], c[1], c[3], ny, 0, nz},
+                             {c[0], c[1], c[2], c[3], 0, c[4]}, {c[0], c[1], c[2], c[3], c[5], nz}};
+  Shell sh;
+  sh.count = 0;
+  sh.first[0] = 0;
+  for (const ShellBox& b : boxes) {
+    const int64_t n = (int64_t)std::max(b.i1 - b.i0, 0) * std::max(b.j1 - b.j0, 0) * std::max(b.k1 - b.k0, 0);
+    if (n == 0) continue;
+    sh.box[sh.count] = b;
+    sh.first[sh.count + 1] = sh.first[sh.count] + blocks_for(n);
+    ++sh.count;
+  }
+  for (int n = sh.count; n < MAX_SHELL_BOXES; ++n) {
+    sh.box[n] = ShellBox{0, 0, 0, 0, 0, 0};
+    sh.first[n + 1] = sh.first[sh.count];
+  }
+  return sh;
+}
+
+// The boxes of a pair of steps: inner (two-step kernel), and the boxes outside which the first
+// step's E and H half steps run.  False: the plan has no room for them.
+bool pair_boxes(const fdtdhip_plan* p, int (&inner)[6], int (&e1)[6], int (&h1)[6]) {
+  int core[6] = {0, p->nx, 0, p->ny, 0, p->nz}, hole[6];
+  if (!p->pmls.empty() && !march_core(p, core, hole)) return false;
+  return shrunk_core(p, core, 2, inner) && shrunk_core(p, core, 3, h1) && shrunk_core(p, core, 4, e1);
+}
+
 template <typename T, int TY, int TYR>
 int pair_step(fdtdhip_plan* p, int64_t q) {
   March2Args<T> m;
   m.E0 = (const T*)p->E; m.H0 = (const T*)p->H;
   m.E1 = (T*)p->E_alt;   m.H1 = (T*)p->H_alt;
   m.nx = p->nx; m.ny = p->ny; m.nz = p->nz;
+  int e1[6], h1[6];
+  if (!pair_boxes(p, m.box, e1, h1)) return fail(-1, "internal: no room for two steps per pass");
+  const bool shell = !p->pmls.empty();
   // the products the one-step kernels form per cell, (Courant number x inverse material),
   // rounded once in T here as there
-  BulkArgs<T> e, h;
-  fill_material<T>(p, true, e);
-  fill_material<T>(p, false, h);
-  if (!e.mat_const || !h.mat_const) return fail(-1, "internal: two steps per launch need constant materials");
+  StepArgs<T> a;
+  if (int rc = step_args<T>(p, q, true, a)) return rc;
+  if (!a.e.mat_const || !a.h.mat_const) return fail(-1, "internal: two steps per pass need constant materials");
   const T sc = (T)p->sc;
-  for (int c = 0; c < 3; ++c) { m.ce[c] = sc * e.bg[c]; m.ch[c] = sc * h.bg[c]; }
+  for (int c = 0; c < 3; ++c) { m.ce[c] = sc * a.e.bg[c]; m.ch[c] = sc * a.h.bg[c]; }
   m.nsrc = 0;
+  ShellSources<T> s1, s2;      // the source points outside `inner`, per step
+  s1.n = s2.n = 0;
   for (const SourceH& s : p->sources) {
     const double w0 = waveform(s, q), w1 = waveform(s, q + 1);
     for (int64_t i = 0; i < s.n; ++i) {
@@ -537,6 +608,14 @@ int pair_step(fdtdhip_plan* p, int64_t q) {
       m.src_c[m.nsrc] = (int)(s.elem_host[i] % 3);
       m.src_v[0][m.nsrc] = (T)(s.profile_host[i] * w0);
       m.src_v[1][m.nsrc] = (T)(s.profile_host[i] * w1);
+      if (shell && !inside_box(p, e1, s.elem_host[i])) {
+        s1.elem[s1.n] = s.elem_host[i];
+        s1.value[s1.n++] = m.src_v[0][m.nsrc];
+      }
+      if (shell && !inside_box(p, m.box, s.elem_host[i])) {
+        s2.elem[s2.n] = s.elem_host[i];
+        s2.value[s2.n++] = m.src_v[1][m.nsrc];
+      }
       ++m.nsrc;
     }
   }
@@ -550,31 +629,57 @@ int pair_step(fdtdhip_plan* p, int64_t q) {
   const int waves = (p->nz + 63) / 64;
   const char* env = getenv("FDTDHIP_MARCH2_ROWS");
   const bool rows = waves <= MARCH2_ROW_WAVES && !(env && atoi(env) == 0);
+  const int planes = m.box[1] - m.box[0], nrows = m.box[3] - m.box[2], ncells = m.box[5] - m.box[4];
   void (*kernel)(March2Args<T>);
   int groups, threads, extra;
   if (rows) {
-    m.tiles = (p->ny + TYR - 1) / TYR;
+    m.tiles = (nrows + TYR - 1) / TYR;
     m.nseg = waves;
     groups = m.tiles;
     threads = 64 * waves;
     extra = 4;
     kernel = step_march2_rows<T, TYR>;
   } else {
-    m.tiles = (p->ny + TY - 1) / TY;
-    m.nseg = (p->nz + MARCH2_ZOWN - 1) / MARCH2_ZOWN;
+    m.tiles = (nrows + TY - 1) / TY;
+    m.nseg = (ncells + MARCH2_ZOWN - 1) / MARCH2_ZOWN;
     groups = (m.tiles * m.nseg + MARCH2_WAVES - 1) / MARCH2_WAVES;
     threads = 64 * MARCH2_WAVES;
     extra = 3;
     kernel = step_march2<T, TY>;
   }
-  m.lx = march_chunk_planes(p->nx, groups, march_slots(p, (const void*)kernel, threads), extra);
+  m.lx = march_chunk_planes(planes, groups, march_slots(p, (const void*)kernel, threads), extra);
   m.band = groups >= 16 ? (groups + 7) / 8 : 0;
-  const dim3 grid(m.band ? 8 * m.band : groups, (p->nx + m.lx - 1) / m.lx, 1), block(threads);
+  const dim3 grid(m.band ? 8 * m.band : groups, (planes + m.lx - 1) / m.lx, 1), block(threads);
   size_t slot;
   if (int rc = span_begin(p, slot)) return rc;
   hipLaunchKernelGGL(kernel, grid, block, 0, p->stream, m);
   HIPCHK(hipGetLastError());
   if (int rc = span_end(p, slot, TIME_PAIR)) return rc;
+  if (shell) {
+    T* EA = (T*)p->E; T* HA = (T*)p->H; T* EB = (T*)p->E_alt; T* HB = (T*)p->H_alt;
+    auto half_step = [&](bool phaseE, const int (&in)[6], const T* F, const T* G, T* out) -> int {
+      const Shell sh = shell_around(p, in);
+      if (!sh.count) return 0;
+      BulkArgs<T> b = phaseE ? a.e : a.h;
+      b.F = const_cast<T*>(F);
+      b.G = G;
+      if (int rc = span_begin(p, slot)) return rc;
+      const dim3 sgrid((unsigned)sh.first[sh.count]), sblock(256);
+      if (phaseE) hipLaunchKernelGGL((shell_E<T, true, false>), sgrid, sblock, 0, p->stream, b, out, sh);
+      else hipLaunchKernelGGL((shell_H<T, true>), sgrid, sblock, 0, p->stream, b, out, sh);
+      HIPCHK(hipGetLastError());
+      return span_end(p, slot, TIME_SHELL);
+    };
+    // first step, in place in A
+    if (int rc = half_step(true, e1, EA, HA, EA)) return rc;
+    if (s1.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, EA, s1);
+    if (int rc = half_step(false, h1, HA, EA, HA)) return rc;
+    // second step, from A into B
+    if (int rc = half_step(true, m.box, EA, HA, EB)) return rc;
+    if (s2.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, EB, s2);
+    if (int rc = half_step(false, m.box, HA, EB, HB)) return rc;
+    HIPCHK(hipGetLastError());
+  }
   std::swap(p->E, p->E_alt);
   std::swap(p->H, p->H_alt);
   p->step_flipped = !p->step_flipped;
@@ -583,19 +688,33 @@ int pair_step(fdtdhip_plan* p, int64_t q) {
 
 }  // namespace
 
-// Whether runs of this plan may advance two steps per launch: a marching plan over the whole
-// grid, both materials constant, whose steps have nothing between them but additive source
-// points -- no detector to read, no curl trace to record (PMLs, objects and slab faces already
-// take the plan to the kernels with a shell; with material arrays to read twice the kernel
-// is slower than two one-step launches: 512^3 float32 2.26 against 1.81 ms per step).  FDTDHIP_MARCH2=0 in the environment: never (read at every call: tests compare
-// the two ways of stepping in one process).
-bool whole_pair_possible(const fdtdhip_plan* p, FusedKind kind) {
-  if (kind != FUSED_MARCH) return false;
+// Whether runs of this plan may advance two steps per pass: a marching plan, both materials
+// constant, whose steps have nothing between them but additive source points -- no detector
+// to read, no curl trace to record, no object, no slab face -- and, with PML faces, room for
+// the boxes of pair_step (with material arrays to read twice the kernel is slower than two
+// one-step launches: 512^3 float32 2.26 against 1.81 ms per step).  FDTDHIP_MARCH2=0 in the
+// environment: never (read at every call: tests compare the two ways of stepping in one process).
+bool whole_pair_possible(const fdtdhip_plan* p, int32_t inner_out[6]) {
   const char* e = getenv("FDTDHIP_MARCH2");
   if (e && atoi(e) == 0) return false;
-  return p->pmls.empty() && p->objs.empty() && !p->H_below && !p->E_above && p->dets.empty() &&
-         p->trace_cursor < 0 && p->nz >= MARCH2_ZOWN && p->mat_const[0] && p->mat_const[1] &&
-         (int64_t)p->ny * p->nz * 3 * (p->dtype == FDTDHIP_F32 ? 4 : 8) < (1ll << 32);   // in-plane byte offsets
+  int inner[6], e1[6], h1[6];
+  if (!(p->objs.empty() && !p->H_below && !p->E_above && p->dets.empty() &&
+        p->trace_cursor < 0 && p->nz >= MARCH2_ZOWN && p->mat_const[0] && p->mat_const[1] &&
+        (int64_t)p->ny * p->nz * 3 * (p->dtype == FDTDHIP_F32 ? 4 : 8) < (1ll << 32) &&   // in-plane byte offsets
+        pair_boxes(p, inner, e1, h1)))
+    return false;
+  // the marching kernels' other conditions and the size from which they pay, with the share of
+  // the cells outside the inner box in place of the one-step march's shell: two steps per pass
+  // pay up to a larger share (256^3 float64 with six ten-cell faces, 26 % outside the inner
+  // box: 0.402 ms per step against 0.505 for half steps and 0.489 for the one-step march)
+  const int64_t in = (int64_t)(inner[1] - inner[0]) * (inner[3] - inner[2]) * (inner[5] - inner[4]);
+  if (fused_kind(p, false, 1.0) != FUSED_MARCH) return false;
+  if (fused_kind(p, false, 0.0) != FUSED_MARCH &&      // (not forced by FDTDHIP_FUSED=2, not a whole grid)
+      (double)(p->cells() - in) > MARCH2_OUTSIDE_SHARE * (double)p->cells())
+    return false;
+  if (inner_out)
+    for (int n = 0; n < 6; ++n) inner_out[n] = inner[n];
+  return true;
 }
 
 int whole_pair_step(fdtdhip_plan* p, int64_t q) {

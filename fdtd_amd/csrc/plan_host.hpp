@@ -438,9 +438,12 @@ int half_plane_energy(fdtdhip_plan* p, int axis, int index, void* outE, void* ou
 
 // ---- launch_whole.hip -------------------------------------------------------------
 bool march_core(const fdtdhip_plan* p, int (&core)[6], int (&hole)[6]);
-FusedKind fused_kind(const fdtdhip_plan* p, bool staged = false);
+// shell_share: the largest share of the cells that the shell of the one-step march may hold
+constexpr double MARCH_SHELL_SHARE = 1.0 / 6;
+FusedKind fused_kind(const fdtdhip_plan* p, bool staged = false, double shell_share = MARCH_SHELL_SHARE);
 int whole_fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind);
-bool whole_pair_possible(const fdtdhip_plan* p, FusedKind kind);   // two steps per launch (yee_march2.hpp)
+// two steps per pass (yee_march2.hpp); inner_out (may be null): the box of the two-step kernel
+bool whole_pair_possible(const fdtdhip_plan* p, int32_t inner_out[6] = nullptr);
 int whole_pair_step(fdtdhip_plan* p, int64_t q);
 int whole_staged_step(fdtdhip_plan* p, int64_t q, int stage);
 int march_slots(fdtdhip_plan* p, const void* kernel, int threads);

@@ -55,6 +55,10 @@ struct March2Args {
   int lx;                          // planes per chunk
   int band;                        // workgroups per XCD (grid x = 8 * band), or 0: plain order
   int tiles, nseg;                 // tiles of TY rows, z segments per row
+  int box[6];                      // x0, x1, y0, y1, z0, z1 of the cells to advance (stored); the
+                                   // two cells around the box on every side are read and, with
+                                   // the cells of the box, evaluated as plain cells: they must
+                                   // be inside the grid's faces or plain themselves
   int nsrc;                        // additive source points: cell, component, value per step
   int src_i[MAX_STEP_SOURCES], src_j[MAX_STEP_SOURCES], src_k[MAX_STEP_SOURCES], src_c[MAX_STEP_SOURCES];
   T src_v[2][MAX_STEP_SOURCES];
@@ -104,6 +108,7 @@ __device__ __forceinline__ void march2_sources(const March2Args<T>& a, int step,
 template <typename T, int NR>
 struct March2Wave {
   int j0, k, i0, i1;
+  int by0, by1;              // rows of the box
   bool kown, hasz, hasz1;
   unsigned koff, zoff;       // the lane's cell and its z neighbour within a row, in bytes (clamped)
   unsigned joff[NR];         // the rows within a plane, in elements (clamped)
@@ -124,7 +129,7 @@ __device__ __forceinline__ void march2_plane(const March2Args<T>& a, const March
   const bool plane = i < nx;
   auto hasy = [&](int r) { return !EDGE || w.j0 - 2 + r > 0; };
   auto hasy1 = [&](int r) { return !EDGE || w.j0 - 2 + r < ny - 1; };
-  auto inside = [&](int r) { return !EDGE || (w.j0 - 2 + r >= 0 && w.j0 - 2 + r < ny); };
+  auto inside = [&](int r) { return w.j0 - 2 + r < w.by1; };   // (owned rows start at the box's first)
   // ---- E' of plane i (a plane past the grid: clamped loads, nothing valid reads the result) ----
   {
     const int64_t pbase = (int64_t)min(i, nx - 1) * w.sx;
@@ -256,13 +261,15 @@ __global__ __launch_bounds__(64 * MARCH2_WAVES) __attribute__((amdgpu_waves_per_
   if (tile >= a.tiles) return;       // (whole waves leave: nothing in this kernel waits for them)
   const int nx = a.nx, ny = a.ny, nz = a.nz;
   March2Wave<T, NR> w;
-  w.k = zseg * MARCH2_ZOWN - 1 + lane;
-  w.kown = w.k >= 0 && w.k < nz && lane >= 1 && lane <= MARCH2_ZOWN;
+  w.k = a.box[4] + zseg * MARCH2_ZOWN - 1 + lane;
+  w.kown = w.k < a.box[5] && lane >= 1 && lane <= MARCH2_ZOWN;
   w.hasz = w.k > 0;
   w.hasz1 = w.k < nz - 1;
-  w.j0 = tile * TY;
-  w.i0 = blockIdx.y * a.lx;
-  w.i1 = min(w.i0 + a.lx, nx);
+  w.by0 = a.box[2];
+  w.by1 = a.box[3];
+  w.j0 = w.by0 + tile * TY;
+  w.i0 = a.box[0] + blockIdx.y * a.lx;
+  w.i1 = min(w.i0 + a.lx, a.box[1]);
   const int is = max(w.i0 - 1, 0);   // first plane evaluated
   const unsigned sy = 3u * (unsigned)nz;
   w.sx = (int64_t)sy * ny;
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(64 * MARCH2_WAVES) __attribute__((amdgpu_waves_per_
 #pragma unroll
   for (int n = 0; n < MAX_STEP_SOURCES; ++n)
     edge |= n < a.nsrc && a.src_j[n] >= w.j0 - 2 && a.src_j[n] < w.j0 - 2 + NR &&
-            a.src_k[n] >= zseg * MARCH2_ZOWN - 1 && a.src_k[n] < zseg * MARCH2_ZOWN + 63;
+            a.src_k[n] >= a.box[4] + zseg * MARCH2_ZOWN - 1 && a.src_k[n] < a.box[4] + zseg * MARCH2_ZOWN + 63;
   T Hp[NR][3], E1p[NR][3], H1p[NR][3], E2p[NR][3];
 #pragma unroll
   for (int r = 0; r < NR; ++r)
@@ -358,7 +365,7 @@ __device__ __forceinline__ void march2_row_plane(const March2Args<T>& a, const M
   const bool first = lane == 0, last = lane == 63;
   auto hasy = [&](int r) { return !EDGE || w.j0 - 2 + r > 0; };
   auto hasy1 = [&](int r) { return !EDGE || w.j0 - 2 + r < ny - 1; };
-  auto inside = [&](int r) { return !EDGE || (w.j0 - 2 + r >= 0 && w.j0 - 2 + r < ny); };
+  auto inside = [&](int r) { return w.j0 - 2 + r < w.by1; };   // (owned rows start at the box's first)
   // ---- E' of plane i ----------------------------------------------------------------------
   // (requesting the loads of plane i+1 here, to travel while the other stages are evaluated:
   // 512^3 float32 1.74 against 1.57 ms per launch -- the registers they occupy, not the wait
@@ -516,12 +523,14 @@ __global__ __launch_bounds__(64 * MARCH2_ROW_WAVES) void step_march2_rows(March2
   const int nx = a.nx, ny = a.ny, nz = a.nz;
   March2Wave<T, NR> w;
   w.k = wave * 64 + lane;
-  w.kown = w.k < nz;
+  w.kown = w.k >= a.box[4] && w.k < a.box[5];
   w.hasz = w.k > 0;
   w.hasz1 = w.k < nz - 1;
-  w.j0 = tile * TY;
-  w.i0 = blockIdx.y * a.lx;
-  w.i1 = min(w.i0 + a.lx, nx);
+  w.by0 = a.box[2];
+  w.by1 = a.box[3];
+  w.j0 = w.by0 + tile * TY;
+  w.i0 = a.box[0] + blockIdx.y * a.lx;
+  w.i1 = min(w.i0 + a.lx, a.box[1]);
   const int is = max(w.i0 - 1, 0);
   const unsigned sy = 3u * (unsigned)nz;
   w.sx = (int64_t)sy * ny;

@@ -81,9 +81,10 @@ __global__ void shell_sources(T* E1, ShellSources<T> s) {
     if (n < s.n) E1[s.elem[n]] += s.value[n];
 }
 
-// E half step of the cells of `b`: a.F (read) -> out.  The arithmetic of bulk_E_generic.
+// E half step of the cells of `b`: a.F (read) -> out (which may be a.F itself: a lane reads its
+// own cell of a.F only, before it writes).  The arithmetic of bulk_E_generic.
 template <typename T, bool HAS_PML, bool HAS_OBJ>
-__global__ __launch_bounds__(256) void shell_E(BulkArgs<T> a, T* __restrict__ out, Shell b) {
+__global__ __launch_bounds__(256) void shell_E(BulkArgs<T> a, T* out, Shell b) {
   int i, j, k;
   if (!shell_lane_cell(b, i, j, k)) return;
   const int64_t sz = 3, sy = 3 * (int64_t)a.nz, sx = sy * a.ny;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void shell_E(BulkArgs<T> a, T* __restrict__ ou
 
 // H half step of the cells of `b`: a.F (read) -> out, driven by a.G (the new E).
 template <typename T, bool HAS_PML>
-__global__ __launch_bounds__(256) void shell_H(BulkArgs<T> a, T* __restrict__ out, Shell b) {
+__global__ __launch_bounds__(256) void shell_H(BulkArgs<T> a, T* out, Shell b) {
   int i, j, k;
   if (!shell_lane_cell(b, i, j, k)) return;
   const int64_t sz = 3, sy = 3 * (int64_t)a.nz, sx = sy * a.ny;

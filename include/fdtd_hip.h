@@ -259,11 +259,19 @@ int fdtdhip_update_H_post_stage(fdtdhip_plan* plan, int64_t q, int stage);
  * kernel per step, first -> second buffers and back; after the call the state is
  * in the first buffers again.  Contents of the second buffers are scratch.
  * Large 3-D plans whose steps have nothing between them but additive source points
- * (no PML, object, detector, recorded curl; both material arrays proven constant by
- * fdtdhip_plan_scan_materials) advance TWO steps per kernel, in groups of four steps;
- * the state after the odd steps of a group then never exists in memory.  The result
- * is the one of the half steps either way, bit for bit. */
+ * (no object, detector, recorded curl; both material arrays proven constant by
+ * fdtdhip_plan_scan_materials) advance TWO steps per pass over memory, in groups of four
+ * steps: the state after the odd steps of a group then never exists in memory (with PML
+ * faces: only for the cells of the faces and the few layers next to them, which take the two
+ * steps one after the other).  The result is the one of the half steps either way, bit for
+ * bit. */
 int fdtdhip_plan_set_step_buffers(fdtdhip_plan* plan, void* E_alt, void* H_alt);
+/* Whether fdtdhip_run would advance this plan two steps per pass (1) or not (0), and the box
+ * {x0,x1,y0,y1,z0,z1} the two-step kernel covers (inner, may be NULL): the whole grid, or with
+ * PML faces the PML-free box shrunk by two cells on every side with a face; the cells outside it
+ * take the two steps one after the other (no reference counterpart; benchmarks use it to
+ * price the kernels). */
+int fdtdhip_plan_two_step_box(fdtdhip_plan* plan, int32_t inner[6]);
 int fdtdhip_plan_set_pml_step_buffer(fdtdhip_plan* plan, int id, void* psiE_alt);
 
 /* nsteps full steps starting at time index q0 (reference fdtd/grid.py:250-273). */

@@ -205,3 +205,97 @@ def test_two_steps_per_launch_on_random_small_grids():
     done = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FDTDHIP_FUSED="2"),
                           capture_output=True, text=True, timeout=280, cwd=here)
     assert done.returncode == 0 and "two steps per launch" in done.stdout, done.stdout[-2000:] + done.stderr[-3000:]
+
+
+_FACES = {
+    # the order DomainBorderPML registers them in, corners shared by three faces
+    "six-faces": [(2, "low", 7), (2, "high", 7), (0, "low", 7), (0, "high", 7), (1, "low", 7), (1, "high", 7)],
+    # another order of the axes, unequal thicknesses, faces missing, one a single cell thick
+    "four-faces": [(1, "high", 5), (0, "low", 9), (2, "low", 1), (2, "high", 11)],
+    "x-faces": [(0, "low", 4), (0, "high", 6)],
+}
+
+
+def _pml_case(dtype, shape, faces, steps, seed=0):
+    """Two steps per pass on a plan with PML faces: the two-step kernel over the inner box, the
+    cells around it by two steps of the shell kernels.  Bitwise equal to explicit half steps
+    (fields and memory variables), the oracle within tolerance.  Sources in the faces, in every
+    layer between the faces and the inner box, and inside it."""
+    fdtd.set_backend(f"hip.{dtype}")
+    nx, ny, nz = shape
+    rs = np.random.RandomState(40 + seed)
+    E0, H0 = 1e-2 * rs.randn(*shape, 3), 1e-2 * rs.randn(*shape, 3)
+    lo = {ax: 0 for ax in range(3)}
+    for axis, side, t in _FACES[faces]:
+        if side == "low":
+            lo[axis] = t
+    sources = [((nx // 2, ny // 2, nz // 2), 11), ((1, 2, 3), 7), ((nx - 2, ny - 1, nz - 3), 9)]
+    for layer in range(6):      # one source per layer inwards from the low faces
+        sources.append(((min(lo[0] + layer, nx - 1), min(lo[1] + layer, ny - 1), min(lo[2] + layer, nz - 1)), 5 + layer))
+    sources.append(((min(lo[0] + 3, nx - 1), ny // 2, nz // 2 + 1), 13))
+
+    def build():
+        g = fdtd.Grid(shape, permittivity=1.3)
+        g.E, g.H = fdtd.backend.array(E0), fdtd.backend.array(H0)
+        for axis, side, t in _FACES[faces]:
+            loc = [slice(None)] * 3
+            loc[axis] = slice(0, t) if side == "low" else slice(-t, None)
+            g[tuple(loc)] = fdtd.PML()
+        for cell, period in sources[:8]:
+            g[cell] = fdtd.PointSource(period=period)
+        return g
+
+    a = build()
+    a._provide_step_buffers()
+    lib = a._ensure_plan()
+    _lib.check(lib.fdtdhip_plan_enable_timing(a._plan, 1))
+    a.run(steps, progress_bar=False)
+    pairs = _pair_launches(a, lib)[0]
+    _lib.check(lib.fdtdhip_plan_enable_timing(a._plan, 0))
+    assert pairs == 2 * (steps // 4), (shape, faces, "the two-step kernel did not run")
+    b = build()
+    for _ in range(steps):
+        b.update_E()
+        b.update_H()
+        b.time_steps_passed += 1
+    os.environ["FDTDHIP_MARCH2_ROWS"] = "0"
+    try:
+        c = build()
+        c.run(steps, progress_bar=False)
+    finally:
+        del os.environ["FDTDHIP_MARCH2_ROWS"]
+    torch.cuda.synchronize()
+    for other, what in ((a, "a workgroup per tile"), (c, "independent waves")):
+        assert torch.equal(other.E, b.E) and torch.equal(other.H, b.H), (dtype, shape, faces, steps, what)
+        for po, pb in zip(other.boundaries, b.boundaries):
+            assert torch.equal(po._psiE, pb._psiE) and torch.equal(po._psiH, pb._psiH), (shape, faces, what)
+    o = orc.OracleGrid(shape, permittivity=1.3)
+    o.E[...], o.H[...] = E0, H0
+    for axis, side, t in _FACES[faces]:
+        o.add_pml(axis, side, t)
+    for cell, period in sources[:8]:
+        o.add_point_source(cell, period=period)
+    o.run(steps)
+    assert rel_l2(host(a.E), o.E) <= TOL[dtype] and rel_l2(host(a.H), o.H) <= TOL[dtype], (shape, faces)
+
+
+def test_two_steps_per_pass_with_pml_faces():
+    """FDTDHIP_FUSED=2 gives grids of any size the marching kernels (read once per process,
+    hence the child)."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (f"import sys\nsys.path[:0] = [{os.path.dirname(here)!r}, {here!r}]\n"
+            "import test_march2 as t\n"
+            "n = 0\n"
+            "for dtype, shape in (('float64', (40, 44, 130)), ('float32', (33, 50, 70)), ('float32', (46, 41, 600))):\n"
+            "    for faces in ('six-faces', 'four-faces', 'x-faces'):\n"
+            "        for steps in (4, 9):\n"
+            "            t._pml_case(dtype, shape, faces, steps, seed=n)\n"
+            "            n += 1\n"
+            "print('two steps per pass with faces:', n, 'cases')\n")
+    done = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FDTDHIP_FUSED="2"),
+                          capture_output=True, text=True, timeout=280, cwd=here)
+    assert done.returncode == 0 and "two steps per pass with faces" in done.stdout, \
+        done.stdout[-2000:] + done.stderr[-3000:]
