@@ -189,8 +189,8 @@ def timed_run(grid, lib, _lib, steps, sync, events=True):
     _lib.check(lib.fdtdhip_plan_get_timing_parts(plan, ms, n))
     _lib.check(lib.fdtdhip_plan_enable_timing(plan, 0))
     core, hole, inner = (ctypes.c_int32 * 6)(), (ctypes.c_int32 * 6)(), (ctypes.c_int32 * 6)()
-    two_step = _lib.check(lib.fdtdhip_plan_two_step_box(plan, inner))
     staged = 1 if taken0 is not None and grid._world > 1 else 0
+    two_step = _lib.check(lib.fdtdhip_plan_two_step_box(plan, staged, inner))
     _lib.check(lib.fdtdhip_plan_whole_step_kind(plan, staged, core, hole))
     whole = n[2] if taken0 is None or grid._world == 1 else grid.whole_steps_taken - taken0
     return elapsed, {"ms": list(ms), "n": list(n), "whole_steps": int(whole),

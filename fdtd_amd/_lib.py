@@ -64,7 +64,8 @@ PROTOTYPES = {
     "fdtdhip_plan_whole_step_kind": (_i, [_p, _i, _pi32, _pi32]),
     "fdtdhip_step_stage": (_i, [_p, _i64, _i]),
     "fdtdhip_step_into": (_i, [_p, _i64]),
-    "fdtdhip_plan_two_step_box": (_i, [_p, C.POINTER(C.c_int32)]),
+    "fdtdhip_plan_two_step_box": (_i, [_p, _i, C.POINTER(C.c_int32)]),
+    "fdtdhip_pair_stage": (_i, [_p, _i64, _i]),
     "fdtdhip_plan_set_object_trace": (_i, [_p, _i, _p, _i64]),
     "fdtdhip_plan_set_object_grad": (_i, [_p, _i, _p]),
     "fdtdhip_plan_set_object_modifier": (_i, [_p, _i, _p, _p, _p]),

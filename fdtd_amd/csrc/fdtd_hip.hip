@@ -529,9 +529,30 @@ int fdtdhip_plan_whole_step_kind(fdtdhip_plan* p, int staged, int32_t core[6], i
   return (int)kind;
 }
 
-int fdtdhip_plan_two_step_box(fdtdhip_plan* p, int32_t inner[6]) {
+int fdtdhip_plan_two_step_box(fdtdhip_plan* p, int staged, int32_t inner[6]) {
   if (!p) return fail(-1, "null plan");
-  return whole_pair_possible(p, inner) ? 1 : 0;
+  return whole_pair_possible(p, inner, staged != 0) ? 1 : 0;
+}
+
+int fdtdhip_pair_stage(fdtdhip_plan* p, int64_t q, int stage) {
+  if (!p) return fail(-1, "null plan");
+  if (stage < 0 || stage > 7) return fail(-1, "stage is 0..7");
+  GUARD(p);
+  if (p->poisoned) return fail(-5, kPoisoned);
+  // (p->stage_next: 0 = no step in progress, 1..3 = fdtdhip_step_stage, 11..17 = this call)
+  const int due = stage == 0 ? 0 : 10 + stage;
+  if (p->stage_next != due)
+    return fail(-1, "fdtdhip_pair_stage: stage " + std::to_string(stage) + " is not the piece that is due");
+  if (stage == 0) {
+    if (!p->E || !p->H || !p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
+    if (!whole_pair_possible(p, nullptr, true))
+      return fail(-1, "this plan cannot take two steps per pass in stages (fdtdhip_plan_two_step_box)");
+  }
+  const int rc = whole_pair_stage(p, q, stage);
+  // (fields and memory variables are advanced in place: a pair that stops half way cannot be repeated)
+  if (rc) p->poisoned = true;
+  else p->stage_next = stage == 7 ? 0 : 10 + stage + 1;
+  return rc;
 }
 
 int fdtdhip_step_stage(fdtdhip_plan* p, int64_t q, int stage) {

@@ -548,9 +548,11 @@ bool inside_box(const fdtdhip_plan* p, const int (&box)[6], int64_t elem) {
 
 // The cells outside `c` as disjoint boxes: x slabs over everything, y slabs between them, z
 // slabs inside.
-Shell shell_around(const fdtdhip_plan* p, const int (&c)[6]) {
-  const int nx = p->nx, ny = p->ny, nz = p->nz;
-  const ShellBox boxes[6] = {{0, c[0], 0, ny, 0, nz}, {c[1], nx, 0, ny, 0, nz},
+// x_from / x_to: the planes below / from there on are left out (an open slab face's plane, which
+// waits for its ghost plane and takes a launch of its own).
+Shell shell_around(const fdtdhip_plan* p, const int (&c)[6], int x_from, int x_to) {
+  const int ny = p->ny, nz = p->nz;
+  const ShellBox boxes[6] = {{x_from, c[0], 0, ny, 0, nz}, {c[1], x_to, 0, ny, 0, nz},
                              {c[0], c[1], 0, c[2], 0, nz}, {c[0], c[1], c[3], ny, 0, nz},
                              {c[0], c[1], c[2], c[3], 0, c[4]}, {c[0], c[1], c[2], c[3], c[5], nz}};
   Shell sh;
@@ -574,19 +576,29 @@ Shell shell_around(const fdtdhip_plan* p, const int (&c)[6]) {
 // step's E and H half steps run.  False: the plan has no room for them.
 bool pair_boxes(const fdtdhip_plan* p, int (&inner)[6], int (&e1)[6], int (&h1)[6]) {
   int core[6] = {0, p->nx, 0, p->ny, 0, p->nz}, hole[6];
-  if (!p->pmls.empty() && !march_core(p, core, hole)) return false;
+  if ((!p->pmls.empty() || p->H_below || p->E_above) && !march_core(p, core, hole)) return false;
   return shrunk_core(p, core, 2, inner) && shrunk_core(p, core, 3, h1) && shrunk_core(p, core, 4, e1);
 }
 
+// The pieces of a pair of steps.  On an x-slab two planes wait for a neighbour's plane in every
+// step -- plane 0 in the E half step, the last plane in the H half step -- and take launches of
+// their own (..._GHOST), so that a caller can place the rest around the four plane exchanges
+// of the pair.  The two-step kernel reads no ghost plane at all (its box keeps three planes
+// away from an open face) and comes first: the first step of the others overwrites what it reads.
+enum { PST_INNER = 1, PST_E1_FREE = 2, PST_E1_GHOST = 4, PST_H1_FREE = 8, PST_H1_GHOST = 16,
+       PST_E2_FREE = 32, PST_E2_GHOST = 64, PST_H2_FREE = 128, PST_H2_GHOST = 256, PST_ALL = 511 };
+
 template <typename T, int TY, int TYR>
-int pair_step(fdtdhip_plan* p, int64_t q) {
+int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
   March2Args<T> m;
   m.E0 = (const T*)p->E; m.H0 = (const T*)p->H;
   m.E1 = (T*)p->E_alt;   m.H1 = (T*)p->H_alt;
   m.nx = p->nx; m.ny = p->ny; m.nz = p->nz;
   int e1[6], h1[6];
   if (!pair_boxes(p, m.box, e1, h1)) return fail(-1, "internal: no room for two steps per pass");
-  const bool shell = !p->pmls.empty();
+  const bool shell = !p->pmls.empty() || p->H_below || p->E_above;
+  const int lo_skip = p->H_below ? 1 : 0, hi_skip = p->E_above ? 1 : 0;
+  const int64_t plane3 = (int64_t)p->ny * p->nz * 3;
   // the products the one-step kernels form per cell, (Courant number x inverse material),
   // rounded once in T here as there
   StepArgs<T> a;
@@ -595,8 +607,9 @@ int pair_step(fdtdhip_plan* p, int64_t q) {
   const T sc = (T)p->sc;
   for (int c = 0; c < 3; ++c) { m.ce[c] = sc * a.e.bg[c]; m.ch[c] = sc * a.h.bg[c]; }
   m.nsrc = 0;
-  ShellSources<T> s1, s2;      // the source points outside `inner`, per step
-  s1.n = s2.n = 0;
+  // the source points outside `inner`, per step; those on plane 0 of a slab open below apart
+  ShellSources<T> s1, s2, g1, g2;
+  s1.n = s2.n = g1.n = g2.n = 0;
   for (const SourceH& s : p->sources) {
     const double w0 = waveform(s, q), w1 = waveform(s, q + 1);
     for (int64_t i = 0; i < s.n; ++i) {
@@ -608,13 +621,16 @@ int pair_step(fdtdhip_plan* p, int64_t q) {
       m.src_c[m.nsrc] = (int)(s.elem_host[i] % 3);
       m.src_v[0][m.nsrc] = (T)(s.profile_host[i] * w0);
       m.src_v[1][m.nsrc] = (T)(s.profile_host[i] * w1);
+      const bool ghost = lo_skip && s.elem_host[i] < plane3;
       if (shell && !inside_box(p, e1, s.elem_host[i])) {
-        s1.elem[s1.n] = s.elem_host[i];
-        s1.value[s1.n++] = m.src_v[0][m.nsrc];
+        ShellSources<T>& ss = ghost ? g1 : s1;
+        ss.elem[ss.n] = s.elem_host[i];
+        ss.value[ss.n++] = m.src_v[0][m.nsrc];
       }
       if (shell && !inside_box(p, m.box, s.elem_host[i])) {
-        s2.elem[s2.n] = s.elem_host[i];
-        s2.value[s2.n++] = m.src_v[1][m.nsrc];
+        ShellSources<T>& ss = ghost ? g2 : s2;
+        ss.elem[ss.n] = s.elem_host[i];
+        ss.value[ss.n++] = m.src_v[1][m.nsrc];
       }
       ++m.nsrc;
     }
@@ -651,14 +667,24 @@ int pair_step(fdtdhip_plan* p, int64_t q) {
   m.band = groups >= 16 ? (groups + 7) / 8 : 0;
   const dim3 grid(m.band ? 8 * m.band : groups, (planes + m.lx - 1) / m.lx, 1), block(threads);
   size_t slot;
-  if (int rc = span_begin(p, slot)) return rc;
-  hipLaunchKernelGGL(kernel, grid, block, 0, p->stream, m);
-  HIPCHK(hipGetLastError());
-  if (int rc = span_end(p, slot, TIME_PAIR)) return rc;
+  if (pieces & PST_INNER) {
+    if (int rc = span_begin(p, slot)) return rc;
+    hipLaunchKernelGGL(kernel, grid, block, 0, p->stream, m);
+    HIPCHK(hipGetLastError());
+    if (int rc = span_end(p, slot, TIME_PAIR)) return rc;
+  }
   if (shell) {
     T* EA = (T*)p->E; T* HA = (T*)p->H; T* EB = (T*)p->E_alt; T* HB = (T*)p->H_alt;
-    auto half_step = [&](bool phaseE, const int (&in)[6], const T* F, const T* G, T* out) -> int {
-      const Shell sh = shell_around(p, in);
+    // ghost = false: the cells outside `in` that wait for no ghost plane; true: the plane that does
+    auto half_step = [&](bool phaseE, bool ghost, const int (&in)[6], const T* F, const T* G, T* out) -> int {
+      Shell sh;
+      if (ghost) {      // plane 0 (E) or the last plane (H), whole
+        const int x = phaseE ? 0 : p->nx - 1;
+        const int none[6] = {x, x + 1, 0, 0, 0, 0};      // (no rows: the y slab above it is the plane)
+        sh = shell_around(p, none, x, x + 1);
+      } else {
+        sh = shell_around(p, in, phaseE ? lo_skip : 0, phaseE ? p->nx : p->nx - hi_skip);
+      }
       if (!sh.count) return 0;
       BulkArgs<T> b = phaseE ? a.e : a.h;
       b.F = const_cast<T*>(F);
@@ -670,19 +696,26 @@ int pair_step(fdtdhip_plan* p, int64_t q) {
       HIPCHK(hipGetLastError());
       return span_end(p, slot, TIME_SHELL);
     };
+    auto add = [&](T* E, const ShellSources<T>& ss) {
+      if (ss.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, E, ss);
+    };
     // first step, in place in A
-    if (int rc = half_step(true, e1, EA, HA, EA)) return rc;
-    if (s1.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, EA, s1);
-    if (int rc = half_step(false, h1, HA, EA, HA)) return rc;
+    if (pieces & PST_E1_FREE) { if (int rc = half_step(true, false, e1, EA, HA, EA)) return rc; add(EA, s1); }
+    if ((pieces & PST_E1_GHOST) && lo_skip) { if (int rc = half_step(true, true, e1, EA, HA, EA)) return rc; add(EA, g1); }
+    if (pieces & PST_H1_FREE) if (int rc = half_step(false, false, h1, HA, EA, HA)) return rc;
+    if ((pieces & PST_H1_GHOST) && hi_skip) if (int rc = half_step(false, true, h1, HA, EA, HA)) return rc;
     // second step, from A into B
-    if (int rc = half_step(true, m.box, EA, HA, EB)) return rc;
-    if (s2.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, EB, s2);
-    if (int rc = half_step(false, m.box, HA, EB, HB)) return rc;
+    if (pieces & PST_E2_FREE) { if (int rc = half_step(true, false, m.box, EA, HA, EB)) return rc; add(EB, s2); }
+    if ((pieces & PST_E2_GHOST) && lo_skip) { if (int rc = half_step(true, true, m.box, EA, HA, EB)) return rc; add(EB, g2); }
+    if (pieces & PST_H2_FREE) if (int rc = half_step(false, false, m.box, HA, EB, HB)) return rc;
+    if ((pieces & PST_H2_GHOST) && hi_skip) if (int rc = half_step(false, true, m.box, HA, EB, HB)) return rc;
     HIPCHK(hipGetLastError());
   }
-  std::swap(p->E, p->E_alt);
-  std::swap(p->H, p->H_alt);
-  p->step_flipped = !p->step_flipped;
+  if (pieces & PST_H2_GHOST) {
+    std::swap(p->E, p->E_alt);
+    std::swap(p->H, p->H_alt);
+    p->step_flipped = !p->step_flipped;
+  }
   return 0;
 }
 
@@ -694,11 +727,12 @@ int pair_step(fdtdhip_plan* p, int64_t q) {
 // the boxes of pair_step (with material arrays to read twice the kernel is slower than two
 // one-step launches: 512^3 float32 2.26 against 1.81 ms per step).  FDTDHIP_MARCH2=0 in the
 // environment: never (read at every call: tests compare the two ways of stepping in one process).
-bool whole_pair_possible(const fdtdhip_plan* p, int32_t inner_out[6]) {
+bool whole_pair_possible(const fdtdhip_plan* p, int32_t inner_out[6], bool staged) {
   const char* e = getenv("FDTDHIP_MARCH2");
   if (e && atoi(e) == 0) return false;
   int inner[6], e1[6], h1[6];
-  if (!(p->objs.empty() && !p->H_below && !p->E_above && p->dets.empty() &&
+  const bool halo = p->H_below || p->E_above;
+  if (!(p->objs.empty() && halo == staged && p->dets.empty() &&
         p->trace_cursor < 0 && p->nz >= MARCH2_ZOWN && p->mat_const[0] && p->mat_const[1] &&
         (int64_t)p->ny * p->nz * 3 * (p->dtype == FDTDHIP_F32 ? 4 : 8) < (1ll << 32) &&   // in-plane byte offsets
         pair_boxes(p, inner, e1, h1)))
@@ -708,8 +742,8 @@ bool whole_pair_possible(const fdtdhip_plan* p, int32_t inner_out[6]) {
   // pay up to a larger share (256^3 float64 with six ten-cell faces, 26 % outside the inner
   // box: 0.402 ms per step against 0.505 for half steps and 0.489 for the one-step march)
   const int64_t in = (int64_t)(inner[1] - inner[0]) * (inner[3] - inner[2]) * (inner[5] - inner[4]);
-  if (fused_kind(p, false, 1.0) != FUSED_MARCH) return false;
-  if (fused_kind(p, false, 0.0) != FUSED_MARCH &&      // (not forced by FDTDHIP_FUSED=2, not a whole grid)
+  if (fused_kind(p, staged, 1.0) != FUSED_MARCH) return false;
+  if (fused_kind(p, staged, 0.0) != FUSED_MARCH &&      // (not forced by FDTDHIP_FUSED=2, not a whole grid)
       (double)(p->cells() - in) > MARCH2_OUTSIDE_SHARE * (double)p->cells())
     return false;
   if (inner_out)
@@ -718,8 +752,16 @@ bool whole_pair_possible(const fdtdhip_plan* p, int32_t inner_out[6]) {
 }
 
 int whole_pair_step(fdtdhip_plan* p, int64_t q) {
-  return DISPATCH(p, (pair_step<float, FDTDHIP_MARCH2_TY32, FDTDHIP_MARCH2_ROWS_TY32>(p, q)),
-                  (pair_step<double, FDTDHIP_MARCH2_TY64, FDTDHIP_MARCH2_ROWS_TY64>(p, q)));
+  return DISPATCH(p, (pair_step<float, FDTDHIP_MARCH2_TY32, FDTDHIP_MARCH2_ROWS_TY32>(p, q, PST_ALL)),
+                  (pair_step<double, FDTDHIP_MARCH2_TY64, FDTDHIP_MARCH2_ROWS_TY64>(p, q, PST_ALL)));
+}
+
+// One of the eight pieces of a pair of steps on an x-slab (fdtdhip_pair_stage).
+int whole_pair_stage(fdtdhip_plan* p, int64_t q, int stage) {
+  static const int pieces[8] = {PST_INNER | PST_E1_FREE, PST_E1_GHOST, PST_H1_FREE, PST_H1_GHOST,
+                                PST_E2_FREE, PST_E2_GHOST, PST_H2_FREE, PST_H2_GHOST};
+  return DISPATCH(p, (pair_step<float, FDTDHIP_MARCH2_TY32, FDTDHIP_MARCH2_ROWS_TY32>(p, q, pieces[stage])),
+                  (pair_step<double, FDTDHIP_MARCH2_TY64, FDTDHIP_MARCH2_ROWS_TY64>(p, q, pieces[stage])));
 }
 
 int whole_fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {

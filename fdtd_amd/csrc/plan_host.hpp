@@ -443,7 +443,8 @@ constexpr double MARCH_SHELL_SHARE = 1.0 / 6;
 FusedKind fused_kind(const fdtdhip_plan* p, bool staged = false, double shell_share = MARCH_SHELL_SHARE);
 int whole_fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind);
 // two steps per pass (yee_march2.hpp); inner_out (may be null): the box of the two-step kernel
-bool whole_pair_possible(const fdtdhip_plan* p, int32_t inner_out[6] = nullptr);
+bool whole_pair_possible(const fdtdhip_plan* p, int32_t inner_out[6] = nullptr, bool staged = false);
+int whole_pair_stage(fdtdhip_plan* p, int64_t q, int stage);   // x-slabs: the pair in eight pieces
 int whole_pair_step(fdtdhip_plan* p, int64_t q);
 int whole_staged_step(fdtdhip_plan* p, int64_t q, int stage);
 int march_slots(fdtdhip_plan* p, const void* kernel, int threads);

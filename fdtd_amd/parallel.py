@@ -81,6 +81,15 @@ class _NativeEngine:
     def step_stage(self, q, stage):
         _lib.check(self.lib.fdtdhip_step_stage(self.plan, q, stage))
 
+    def pairs_possible(self):
+        """Whether this slab's plan can advance two steps per pass in stages
+        (``fdtdhip_pair_stage``): whole steps possible, and nothing between two steps but
+        additive source points -- no detector, object or recorded curl -- constant materials."""
+        return self.lib.fdtdhip_plan_two_step_box(self.plan, 1, None) == 1
+
+    def pair_stage(self, q, stage):
+        _lib.check(self.lib.fdtdhip_pair_stage(self.plan, q, stage))
+
     def defer_currents(self, plane):
         """Current detectors wait for ``plane`` (the H plane under this slab) instead of
         being read with the other detectors; None: read them with the others."""
@@ -134,6 +143,7 @@ class SlabGrid(Grid):
         self._send_E = bd.zeros(plane) if self._rank > 0 else None
         self._engine = (engine_factory or _NativeEngine)(self)
         self.whole_steps_taken = 0    # steps advanced by the whole-step kernel (diagnostics)
+        self.pair_steps_taken = 0     # of those: advanced two per pass
 
     # ------------------------------------------------------------ decomposition
     def _plane_counts(self):
@@ -368,19 +378,53 @@ class SlabGrid(Grid):
         eng.step_stage(q, 3)
 
     def _whole_steps_agreed(self, eng, n):
-        """Collective: whether the coming ``n`` steps are taken as whole steps in stages.  The
-        two ways of stepping exchange planes at different moments, so every rank has to take
-        the same one: the one-launch step only if every rank's plan can."""
+        """Collective: how the coming ``n`` steps are taken -- 0: half steps, 1: whole steps in
+        stages, 2: two steps per pass in stages where four or more remain, whole steps
+        otherwise.  The ways of stepping exchange planes at different moments, so every rank has
+        to take the same one: the fastest that every rank's plan can."""
         if n < 2 or not hasattr(eng, "whole_steps_possible"):
-            return False
-        mine = (getattr(self, "_step_buffers", None) is not None and not self._x_wrap
-                and not self._currents_cross_slabs and eng.whole_steps_possible())
+            return 0
+        mine = 0
+        if (getattr(self, "_step_buffers", None) is not None and not self._x_wrap
+                and not self._currents_cross_slabs and eng.whole_steps_possible()):
+            mine = 2 if n >= 4 and hasattr(eng, "pairs_possible") and eng.pairs_possible() else 1
         if self._world == 1:
             return mine
         on_device = self._backend_name == "nccl"
-        flag = torch.tensor([1 if mine else 0], device=bd.device if on_device else "cpu")
+        flag = torch.tensor([mine], device=bd.device if on_device else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._group)
-        return bool(flag.item())
+        return int(flag.item())
+
+    def _pair_of_steps(self, eng, q, cur, alt):
+        """Steps ``q`` and ``q + 1`` from the buffers ``cur`` = (E, H) into ``alt`` in eight pieces
+        around the four plane exchanges (``fdtdhip_pair_stage``).  The two-step kernel takes the
+        cells three or more planes away from the slab's open faces (and from PMLs) in one pass
+        and needs no neighbour's plane; the others take the two steps one after the other, the
+        first in place in ``cur``, each plane exchange hidden behind the launches that do not
+        wait for it."""
+        r, p = self._rank, self._world
+        up = lambda plane: self._tangential(plane, self._send_H) if r < p - 1 else None      # noqa: E731
+        down = lambda plane: self._tangential(plane, self._send_E) if r > 0 else None        # noqa: E731
+        ex = self._start_exchange(up(cur[1][-1]), r + 1, self._H_below, r - 1)
+        eng.pair_stage(q, 0)
+        if ex is not None:
+            ex.wait()
+        eng.pair_stage(q, 1)
+        ex = self._start_exchange(down(cur[0][0]), r - 1, self._E_above, r + 1)
+        eng.pair_stage(q, 2)
+        if ex is not None:
+            ex.wait()
+        eng.pair_stage(q, 3)
+        ex = self._start_exchange(up(cur[1][-1]), r + 1, self._H_below, r - 1)
+        eng.pair_stage(q, 4)
+        if ex is not None:
+            ex.wait()
+        eng.pair_stage(q, 5)
+        ex = self._start_exchange(down(alt[0][0]), r - 1, self._E_above, r + 1)
+        eng.pair_stage(q, 6)
+        if ex is not None:
+            ex.wait()
+        eng.pair_stage(q, 7)
 
     def _native_run(self, lib, n):
         eng = self._engine
@@ -389,11 +433,17 @@ class SlabGrid(Grid):
         s = 0
         # (recorded runs too: the E half step of the box around the objects, which the shell
         # launches take, writes the curl traces the reverse sweep reads)
-        if self._whole_steps_agreed(eng, n):
+        how = self._whole_steps_agreed(eng, n)
+        if how:
             # pairs of whole steps, first -> second buffers and back: the state ends in the
             # tensors the user holds; an odd last step runs as two half steps
             cur = (self.E.detach(), self.H.detach())
             alt = self._step_buffers
+            while how == 2 and s + 3 < n:      # two steps per pass, in twos
+                self._pair_of_steps(eng, self.time_steps_passed + s, cur, alt)
+                self._pair_of_steps(eng, self.time_steps_passed + s + 2, alt, cur)
+                s += 4
+                self.pair_steps_taken += 4
             while s + 1 < n:
                 self._whole_step(eng, self.time_steps_passed + s, cur, alt)
                 self._whole_step(eng, self.time_steps_passed + s + 1, alt, cur)

@@ -271,7 +271,24 @@ int fdtdhip_plan_set_step_buffers(fdtdhip_plan* plan, void* E_alt, void* H_alt);
  * PML faces the PML-free box shrunk by two cells on every side with a face; the cells outside it
  * take the two steps one after the other (no reference counterpart; benchmarks use it to
  * price the kernels). */
-int fdtdhip_plan_two_step_box(fdtdhip_plan* plan, int32_t inner[6]);
+int fdtdhip_plan_two_step_box(fdtdhip_plan* plan, int staged, int32_t inner[6]);
+/* A pair of steps (time indices q, q + 1) of an x-slab in eight pieces around its four plane
+ * exchanges (`staged` != 0 above asks whether the plan can take them), the counterpart of
+ * fdtdhip_step_stage for two steps per pass.  With the fields in the first buffers A and the
+ * second buffers B:
+ *   stage 0  the two-step kernel over the inner box (A -> B; it keeps three planes away from an
+ *            open face and reads no ghost plane), then the first step's E half step of the cells
+ *            outside it except plane 0, in place in A          -- while H_below (step q) travels;
+ *   stage 1  E half step of plane 0 (reads H_below).  Its new (Ey, Ez), in A, go to the rank below;
+ *   stage 2  the first step's H half step except the last plane, in place in A;
+ *   stage 3  H half step of the last plane (reads E_above).  Its new (Hy, Hz), in A, go to the rank above;
+ *   stage 4  the second step's E half step except plane 0, A -> B;
+ *   stage 5  E half step of plane 0 (reads H_below of step q + 1).  Its new (Ey, Ez), in B, go below;
+ *   stage 6  the second step's H half step except the last plane;
+ *   stage 7  H half step of the last plane (reads E_above of step q + 1); then the buffers swap.
+ * Results equal four half steps bit for bit.  Take pairs in twos so that the state ends in the
+ * first buffers.  The stages are accepted in their order only; a failed stage poisons the plan. */
+int fdtdhip_pair_stage(fdtdhip_plan* plan, int64_t q, int stage);
 int fdtdhip_plan_set_pml_step_buffer(fdtdhip_plan* plan, int id, void* psiE_alt);
 
 /* nsteps full steps starting at time index q0 (reference fdtd/grid.py:250-273). */

@@ -296,17 +296,20 @@ def test_staged_steps_over_rccl_equal_half_steps_bitwise():
 
     tool = os.path.join(os.path.dirname(HERE), "tools", "slab_step_cost.py")
     sums = {}
-    for mode, env in (("staged", {}), ("half steps", {"FDTDHIP_FUSED": "0"})):
+    for mode, env in (("two steps per pass", {}), ("staged", {"FDTDHIP_MARCH2": "0"}),
+                      ("half steps", {"FDTDHIP_FUSED": "0"})):
         port = str(slab_support.free_port())
-        base = {k: v for k, v in os.environ.items() if k != "FDTDHIP_FUSED"}   # the library's own choice
+        base = {k: v for k, v in os.environ.items() if k not in ("FDTDHIP_FUSED", "FDTDHIP_MARCH2")}   # the library's own choice
         done = subprocess.run([sys.executable, tool, "21", "small"], capture_output=True, text=True, timeout=280,
                               env=dict(base, MASTER_PORT=port, **env))
         assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-3000:]
         line = [ln for ln in done.stdout.splitlines() if ln.startswith("state checksum")][0]
-        taken = int(done.stdout.split("whole steps taken")[1].split()[0])
-        assert (taken > 0) == (mode == "staged"), done.stdout[-500:]
+        taken = int(done.stdout.split("whole steps taken")[1].split(",")[0])
+        pairs = int(done.stdout.split("of them two per pass")[1].split()[0])
+        assert (taken > 0) == (mode != "half steps"), done.stdout[-500:]
+        assert (pairs > 0) == (mode == "two steps per pass"), done.stdout[-500:]
         sums[mode] = line
-    assert sums["staged"] == sums["half steps"], sums
+    assert sums["staged"] == sums["half steps"] == sums["two steps per pass"], sums
 
 
 @pytest.mark.gpu
@@ -490,7 +493,10 @@ def test_random_scenes_on_slabs_gpu(tmp_path):
     _fuzz(3, 400, 90, True, tmp_path)
 
 
-def _large_slab_worker(rank, world, port, out):
+def _large_slab_worker(rank, world, port, out, plain=False):
+    """plain: no object and no detector -- nothing between the steps but the source points, so
+    that the slabs may take two steps per pass (11 steps: two pairs of passes, a pair of whole
+    steps, one step of half steps)."""
     import torch.distributed as dist
 
     import fdtd_amd as fdtd
@@ -507,22 +513,34 @@ def _large_slab_worker(rank, world, port, out):
         grid[64 * world // 2, 60, 250] = fdtd.PointSource(period=17)      # first plane of a slab
         grid[64 * world // 2 - 1, 3, 300] = fdtd.PointSource(period=23)   # last plane, inside a PML
         grid[20, 64, 100] = fdtd.PointSource(period=11)
-        grid[64 * world - 30:64 * world - 10, 30:50, 40:90] = fdtd.AbsorbingObject(
-            permittivity=2.0, conductivity=1e-2)
+        if plain:      # sources in every layer next to an open face and next to a PML
+            for n in range(1, 5):      # (eight source points in all: the whole-step kernels' limit)
+                grid[64 + n, 4 + n, 4 + n] = fdtd.PointSource(period=5 + n)
+            grid[64 * world // 2 - 3, 90, 507] = fdtd.PointSource(period=13)
+        else:
+            grid[64 * world - 30:64 * world - 10, 30:50, 40:90] = fdtd.AbsorbingObject(
+                permittivity=2.0, conductivity=1e-2)
         det = fdtd.LineDetector()
-        grid[5:64 * world - 5, 64, 256] = det
+        if not plain:
+            grid[5:64 * world - 5, 64, 256] = det
         gen = torch.Generator(device=grid.E.device).manual_seed(77 + rank)
         with torch.no_grad():
             for f in (grid.E, grid.H):
                 f.uniform_(-1e-3, 1e-3, generator=gen)
-            grid.run(7, progress_bar=False)    # three pairs of whole steps, one step of half steps
+            # (7: three pairs of whole steps, one step of half steps)
+            grid.run(11 if plain else 7, progress_bar=False)
         torch.cuda.synchronize()
         E, H = grid.gather("E"), grid.gather("H")
+        psi = [fdtd.backend.numpy(torch.cat([b._psiE.reshape(-1), b._psiH.reshape(-1)]))
+               for b in grid.boundaries if getattr(b, "_active", False)]
         parts = [None] * world
-        dist.all_gather_object(parts, (fdtd.backend.numpy(torch.stack(det.E)), grid.whole_steps_taken))
+        readings = fdtd.backend.numpy(torch.stack(det.E)) if not plain else np.zeros((1, 0, 3))
+        dist.all_gather_object(parts, (readings, grid.whole_steps_taken, grid.pair_steps_taken,
+                                       np.concatenate(psi) if psi else np.zeros(0)))
         if rank == 0:
             np.savez(out, E=E, H=H, det=np.concatenate([p[0] for p in parts], axis=1),
-                     whole=np.array([p[1] for p in parts]))
+                     whole=np.array([p[1] for p in parts]), pairs=np.array([p[2] for p in parts]),
+                     psi=np.concatenate([p[3] for p in parts]))
     finally:
         dist.destroy_process_group()
 
@@ -546,6 +564,33 @@ def test_large_slabs_take_whole_steps_by_default_and_equal_half_steps_bitwise(tm
     for name in ("E", "H", "det"):
         assert np.array_equal(runs["default"][name], runs["0"][name]), name
     assert np.abs(runs["default"]["E"]).max() > 0
+
+
+@pytest.mark.gpu
+def test_large_slabs_take_two_steps_per_pass_and_equal_half_steps_bitwise(tmp_path, monkeypatch):
+    """The same slabs without object and detector: nothing between their steps but source
+    points, so each pair of steps is one pass of the two-step kernel over the cells three or
+    more planes away from the open faces and the PMLs, and two steps of the shell kernels
+    over the others around the four plane exchanges (fdtdhip_pair_stage) -- against whole steps
+    in stages (FDTDHIP_MARCH2=0) and half steps (FDTDHIP_FUSED=0), bit for bit, fields and
+    memory variables."""
+    runs = {}
+    monkeypatch.delenv("FDTDHIP_FUSED", raising=False)
+    for mode, env in (("pairs", {}), ("whole", {"FDTDHIP_MARCH2": "0"}), ("half", {"FDTDHIP_FUSED": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = str(tmp_path / f"plain_{mode}.npz")
+        mp.spawn(_large_slab_worker, args=(3, slab_support.free_port(), out, True), nprocs=3, join=True)
+        runs[mode] = np.load(out)
+        for k in env:
+            monkeypatch.delenv(k)
+    assert list(runs["pairs"]["pairs"]) == [8, 8, 8] and list(runs["pairs"]["whole"]) == [10, 10, 10]
+    assert list(runs["whole"]["pairs"]) == [0, 0, 0] and list(runs["whole"]["whole"]) == [10, 10, 10]
+    assert list(runs["half"]["whole"]) == [0, 0, 0]
+    for name in ("E", "H", "psi"):
+        assert np.array_equal(runs["pairs"][name], runs["half"][name]), name
+        assert np.array_equal(runs["whole"][name], runs["half"][name]), name
+    assert np.abs(runs["pairs"]["E"]).max() > 0 and np.abs(runs["pairs"]["psi"]).max() > 0
 
 
 @pytest.mark.gpu

@@ -4,7 +4,8 @@ rank is its own neighbour on both sides (a one-rank RCCL group sending the plane
 itself), so the exchanges cost what RCCL's send/recv kernels and their stream
 synchronisation cost on one device -- no xGMI, but every launch, wait and copy of the real
 schedule.  FDTDHIP_FUSED=0 in the environment: two half-step launches per step (with the
-interior / boundary-plane split); default: whole steps in stages.
+interior / boundary-plane split); FDTDHIP_MARCH2=0: whole steps in stages; default: two steps per
+pass in stages where the plan allows.
 
     python tools/slab_step_cost.py [steps] [workload: m4 | m4end (the first slab: a PML on its
                                                      low x face, one neighbour) | m3v | small]
@@ -57,8 +58,9 @@ class InteriorSlab(SlabGrid):
         return 0
 
     def _whole_steps_agreed(self, eng, n):
-        return (n >= 2 and getattr(self, "_step_buffers", None) is not None
-                and eng.whole_steps_possible())
+        if not (n >= 2 and getattr(self, "_step_buffers", None) is not None and eng.whole_steps_possible()):
+            return 0
+        return 2 if n >= 4 and eng.pairs_possible() else 1
 
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -99,7 +101,8 @@ bits = int(g.E.view(torch.int32).to(torch.int64).sum()) ^ (int(g.H.view(torch.in
 print(f"state checksum {bits:#x}, max|E| {float(g.E.abs().max()):.6e}")
 print(f"{workload} interior slab, FDTDHIP_FUSED={os.environ.get('FDTDHIP_FUSED', 'default')}: "
       f"{(t2 - t0) / steps * 1e3:.3f} ms/step = {cells * steps / (t2 - t0) / 1e9:.1f} Gcells/s, "
-      f"host enqueue {(t1 - t0) / steps * 1e3:.3f} ms/step, whole steps taken {g.whole_steps_taken}",
+      f"host enqueue {(t1 - t0) / steps * 1e3:.3f} ms/step, whole steps taken {g.whole_steps_taken}, "
+      f"of them two per pass {g.pair_steps_taken}",
       flush=True)
 if adjoint:
     nb = int(sys.argv[4]) if len(sys.argv) > 4 else 20
