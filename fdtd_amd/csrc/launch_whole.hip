@@ -644,11 +644,21 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
   // (step_march2).  FDTDHIP_MARCH2_ROWS=0 in the environment: independent waves always (tests).
   const int waves = (p->nz + 63) / 64;
   const char* env = getenv("FDTDHIP_MARCH2_ROWS");
-  const bool rows = waves <= MARCH2_ROW_WAVES && !(env && atoi(env) == 0);
+  // (float32 rows of up to 1024 cells: 16 waves with two-row tiles)
+  const bool rows16 = sizeof(T) == 4 && waves > MARCH2_ROW_WAVES && waves <= 16 && !(env && atoi(env) == 0);
+  const bool rows = (waves <= MARCH2_ROW_WAVES && !(env && atoi(env) == 0)) || rows16;
   const int planes = m.box[1] - m.box[0], nrows = m.box[3] - m.box[2], ncells = m.box[5] - m.box[4];
   void (*kernel)(March2Args<T>);
   int groups, threads, extra;
-  if (rows) {
+  if (rows16) {
+    m.tiles = (nrows + 1) / 2;
+    m.nseg = waves;
+    groups = m.tiles;
+    threads = 64 * waves;
+    extra = 4;
+    if constexpr (sizeof(T) == 4) kernel = step_march2_rows<T, 2, 16>;
+    else return fail(-1, "internal: no 16-wave two-step kernel in float64");
+  } else if (rows) {
     m.tiles = (nrows + TYR - 1) / TYR;
     m.nseg = waves;
     groups = m.tiles;

@@ -346,16 +346,16 @@ __device__ __forceinline__ double wave_below(double v) {
 
 // What crosses the ends of the waves, per parity of the plane: components x and y of each row.
 // Slot v holds what wave v - 1's last lane and wave v's first lane wrote.
-template <typename T, int TY>
+template <typename T, int TY, int MW>
 struct March2Exchange {
-  T e1[2][MARCH2_ROW_WAVES + 1][TY + 4][2];   // E' of the first lanes (for the last lane of the wave before)
-  T h1[2][MARCH2_ROW_WAVES + 1][TY + 4][2];   // H' of the last lanes (for the first lane of the wave after)
-  T e2[2][MARCH2_ROW_WAVES + 1][TY + 4][2];   // E'' of the first lanes
+  T e1[2][MW + 1][TY + 4][2];   // E' of the first lanes (for the last lane of the wave before)
+  T h1[2][MW + 1][TY + 4][2];   // H' of the last lanes (for the first lane of the wave after)
+  T e2[2][MW + 1][TY + 4][2];   // E'' of the first lanes
 };
 
-template <typename T, int TY, bool EDGE>
+template <typename T, int TY, int MW, bool EDGE>
 __device__ __forceinline__ void march2_row_plane(const March2Args<T>& a, const March2Wave<T, TY + 4>& w,
-                                                 March2Exchange<T, TY>& x, int wave, int lane, int i,
+                                                 March2Exchange<T, TY, MW>& x, int wave, int lane, int i,
                                                  T (&Hp)[TY + 4][3], T (&E1a)[TY + 4][3], T (&E1b)[TY + 4][3],
                                                  T (&H1a)[TY + 4][3], T (&H1b)[TY + 4][3], T (&E2a)[TY + 4][3]) {
   constexpr int NR = TY + 4;
@@ -511,12 +511,13 @@ __device__ __forceinline__ void march2_row_plane(const March2Args<T>& a, const M
   __syncthreads();
 }
 
-// Workgroup = the waves of the z rows of one tile (blockDim.x = 64 x waves <= 512), grid x = tiles
-// (in bands per XCD), grid y = chunks of planes.
-template <typename T, int TY>
-__global__ __launch_bounds__(64 * MARCH2_ROW_WAVES) void step_march2_rows(March2Args<T> a) {
+// Workgroup = the waves of the z rows of one tile (blockDim.x = 64 x waves <= 64 MW), grid x =
+// tiles (in bands per XCD), grid y = chunks of planes.  MW = 8: up to 256 registers per lane;
+// MW = 16 (z rows of up to 1024 cells): 128, which tiles of two rows fit in float32.
+template <typename T, int TY, int MW = MARCH2_ROW_WAVES>
+__global__ __launch_bounds__(64 * MW) void step_march2_rows(March2Args<T> a) {
   constexpr int NR = TY + 4;
-  __shared__ March2Exchange<T, TY> x;
+  __shared__ March2Exchange<T, TY, MW> x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = a.band > 0 ? (int)(blockIdx.x & 7) * a.band + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   if (tile >= a.tiles) return;       // (the whole workgroup)
@@ -564,9 +565,9 @@ __global__ __launch_bounds__(64 * MARCH2_ROW_WAVES) void step_march2_rows(March2
   // the barriers pair up)
   const int iend = min(w.i1 + 2, nx + 2);
   if (edge) {
-    for (int i = is; i <= iend; ++i) march2_row_plane<T, TY, true>(a, w, x, wave, lane, i, Hp, E1a, E1b, H1a, H1b, E2a);
+    for (int i = is; i <= iend; ++i) march2_row_plane<T, TY, MW, true>(a, w, x, wave, lane, i, Hp, E1a, E1b, H1a, H1b, E2a);
   } else {
-    for (int i = is; i <= iend; ++i) march2_row_plane<T, TY, false>(a, w, x, wave, lane, i, Hp, E1a, E1b, H1a, H1b, E2a);
+    for (int i = is; i <= iend; ++i) march2_row_plane<T, TY, MW, false>(a, w, x, wave, lane, i, Hp, E1a, E1b, H1a, H1b, E2a);
   }
 }
 
