@@ -550,11 +550,14 @@ bool inside_box(const fdtdhip_plan* p, const int (&box)[6], int64_t elem) {
 // slabs inside.
 // x_from / x_to: the planes below / from there on are left out (an open slab face's plane, which
 // waits for its ghost plane and takes a launch of its own).
-Shell shell_around(const fdtdhip_plan* p, const int (&c)[6], int x_from, int x_to) {
+// island: one more box inside `c` (objects and the layers around them), or null.
+Shell shell_around(const fdtdhip_plan* p, const int (&c)[6], int x_from, int x_to, const int* island = nullptr) {
   const int ny = p->ny, nz = p->nz;
-  const ShellBox boxes[6] = {{x_from, c[0], 0, ny, 0, nz}, {c[1], x_to, 0, ny, 0, nz},
+  const ShellBox none{0, 0, 0, 0, 0, 0};
+  const ShellBox boxes[7] = {{x_from, c[0], 0, ny, 0, nz}, {c[1], x_to, 0, ny, 0, nz},
                              {c[0], c[1], 0, c[2], 0, nz}, {c[0], c[1], c[3], ny, 0, nz},
-                             {c[0], c[1], c[2], c[3], 0, c[4]}, {c[0], c[1], c[2], c[3], c[5], nz}};
+                             {c[0], c[1], c[2], c[3], 0, c[4]}, {c[0], c[1], c[2], c[3], c[5], nz},
+                             island ? ShellBox{island[0], island[1], island[2], island[3], island[4], island[5]} : none};
   Shell sh;
   sh.count = 0;
   sh.first[0] = 0;
@@ -572,12 +575,32 @@ Shell shell_around(const fdtdhip_plan* p, const int (&c)[6], int x_from, int x_t
   return sh;
 }
 
-// The boxes of a pair of steps: inner (two-step kernel), and the boxes outside which the first
-// step's E and H half steps run.  False: the plan has no room for them.
-bool pair_boxes(const fdtdhip_plan* p, int (&inner)[6], int (&e1)[6], int (&h1)[6]) {
-  int core[6] = {0, p->nx, 0, p->ny, 0, p->nz}, hole[6];
-  if ((!p->pmls.empty() || p->H_below || p->E_above) && !march_core(p, core, hole)) return false;
-  return shrunk_core(p, core, 2, inner) && shrunk_core(p, core, 3, h1) && shrunk_core(p, core, 4, e1);
+// `hole` grown by m cells on every side and cut to `box`; all zeros if nothing is left (or there is no hole).
+void grown_hole(const int (&hole)[6], int m, const int (&box)[6], int (&out)[6]) {
+  bool any = hole[1] > hole[0];
+  for (int ax = 0; ax < 3 && any; ++ax) {
+    out[2 * ax] = std::max(hole[2 * ax] - m, box[2 * ax]);
+    out[2 * ax + 1] = std::min(hole[2 * ax + 1] + m, box[2 * ax + 1]);
+    any = out[2 * ax + 1] > out[2 * ax];
+  }
+  if (!any)
+    for (int n = 0; n < 6; ++n) out[n] = 0;
+}
+
+// The boxes of a pair of steps: inner (two-step kernel) and the boxes outside which the first
+// step's E and H half steps run; with objects, the box that holds them (clipped to the core)
+// grown by two, four and three cells: an island inside each of those boxes that belongs to the
+// cells outside it.  False: the plan has no room for them.
+struct PairBoxes { int inner[6], e1[6], h1[6], hole2[6], hole4[6], hole3[6]; };
+bool pair_boxes(const fdtdhip_plan* p, PairBoxes& b) {
+  int core[6] = {0, p->nx, 0, p->ny, 0, p->nz}, hole[6] = {0, 0, 0, 0, 0, 0};
+  if ((!p->pmls.empty() || !p->objs.empty() || p->H_below || p->E_above) && !march_core(p, core, hole)) return false;
+  if (!(shrunk_core(p, core, 2, b.inner) && shrunk_core(p, core, 3, b.h1) && shrunk_core(p, core, 4, b.e1)))
+    return false;
+  grown_hole(hole, 2, b.inner, b.hole2);
+  grown_hole(hole, 3, b.h1, b.hole3);
+  grown_hole(hole, 4, b.e1, b.hole4);
+  return true;
 }
 
 // The pieces of a pair of steps.  On an x-slab two planes wait for a neighbour's plane in every
@@ -594,9 +617,13 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
   m.E0 = (const T*)p->E; m.H0 = (const T*)p->H;
   m.E1 = (T*)p->E_alt;   m.H1 = (T*)p->H_alt;
   m.nx = p->nx; m.ny = p->ny; m.nz = p->nz;
-  int e1[6], h1[6];
-  if (!pair_boxes(p, m.box, e1, h1)) return fail(-1, "internal: no room for two steps per pass");
-  const bool shell = !p->pmls.empty() || p->H_below || p->E_above;
+  PairBoxes pb;
+  if (!pair_boxes(p, pb)) return fail(-1, "internal: no room for two steps per pass");
+  for (int n = 0; n < 6; ++n) { m.box[n] = pb.inner[n]; m.hole[n] = pb.hole2[n]; }
+  const int (&e1)[6] = pb.e1;
+  const int (&h1)[6] = pb.h1;
+  const bool obj = !p->objs.empty();
+  const bool shell = !p->pmls.empty() || obj || p->H_below || p->E_above;
   const int lo_skip = p->H_below ? 1 : 0, hi_skip = p->E_above ? 1 : 0;
   const int64_t plane3 = (int64_t)p->ny * p->nz * 3;
   // the products the one-step kernels form per cell, (Courant number x inverse material),
@@ -622,12 +649,12 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
       m.src_v[0][m.nsrc] = (T)(s.profile_host[i] * w0);
       m.src_v[1][m.nsrc] = (T)(s.profile_host[i] * w1);
       const bool ghost = lo_skip && s.elem_host[i] < plane3;
-      if (shell && !inside_box(p, e1, s.elem_host[i])) {
+      if (shell && (!inside_box(p, e1, s.elem_host[i]) || inside_box(p, pb.hole4, s.elem_host[i]))) {
         ShellSources<T>& ss = ghost ? g1 : s1;
         ss.elem[ss.n] = s.elem_host[i];
         ss.value[ss.n++] = m.src_v[0][m.nsrc];
       }
-      if (shell && !inside_box(p, m.box, s.elem_host[i])) {
+      if (shell && (!inside_box(p, m.box, s.elem_host[i]) || inside_box(p, pb.hole2, s.elem_host[i]))) {
         ShellSources<T>& ss = ghost ? g2 : s2;
         ss.elem[ss.n] = s.elem_host[i];
         ss.value[ss.n++] = m.src_v[1][m.nsrc];
@@ -686,14 +713,17 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
   if (shell) {
     T* EA = (T*)p->E; T* HA = (T*)p->H; T* EB = (T*)p->E_alt; T* HB = (T*)p->H_alt;
     // ghost = false: the cells outside `in` that wait for no ghost plane; true: the plane that does
-    auto half_step = [&](bool phaseE, bool ghost, const int (&in)[6], const T* F, const T* G, T* out) -> int {
+    const bool pml = !p->pmls.empty();
+    auto half_step = [&](bool phaseE, bool ghost, const int (&in)[6], const int (&island)[6],
+                         const T* F, const T* G, T* out) -> int {
       Shell sh;
       if (ghost) {      // plane 0 (E) or the last plane (H), whole
         const int x = phaseE ? 0 : p->nx - 1;
         const int none[6] = {x, x + 1, 0, 0, 0, 0};      // (no rows: the y slab above it is the plane)
         sh = shell_around(p, none, x, x + 1);
       } else {
-        sh = shell_around(p, in, phaseE ? lo_skip : 0, phaseE ? p->nx : p->nx - hi_skip);
+        sh = shell_around(p, in, phaseE ? lo_skip : 0, phaseE ? p->nx : p->nx - hi_skip,
+                          island[1] > island[0] ? island : nullptr);
       }
       if (!sh.count) return 0;
       BulkArgs<T> b = phaseE ? a.e : a.h;
@@ -701,8 +731,12 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
       b.G = G;
       if (int rc = span_begin(p, slot)) return rc;
       const dim3 sgrid((unsigned)sh.first[sh.count]), sblock(256);
-      if (phaseE) hipLaunchKernelGGL((shell_E<T, true, false>), sgrid, sblock, 0, p->stream, b, out, sh);
-      else hipLaunchKernelGGL((shell_H<T, true>), sgrid, sblock, 0, p->stream, b, out, sh);
+      if (phaseE && pml && obj) hipLaunchKernelGGL((shell_E<T, true, true>), sgrid, sblock, 0, p->stream, b, out, sh);
+      else if (phaseE && pml) hipLaunchKernelGGL((shell_E<T, true, false>), sgrid, sblock, 0, p->stream, b, out, sh);
+      else if (phaseE && obj) hipLaunchKernelGGL((shell_E<T, false, true>), sgrid, sblock, 0, p->stream, b, out, sh);
+      else if (phaseE) hipLaunchKernelGGL((shell_E<T, false, false>), sgrid, sblock, 0, p->stream, b, out, sh);
+      else if (pml) hipLaunchKernelGGL((shell_H<T, true>), sgrid, sblock, 0, p->stream, b, out, sh);
+      else hipLaunchKernelGGL((shell_H<T, false>), sgrid, sblock, 0, p->stream, b, out, sh);
       HIPCHK(hipGetLastError());
       return span_end(p, slot, TIME_SHELL);
     };
@@ -710,15 +744,15 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
       if (ss.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, E, ss);
     };
     // first step, in place in A
-    if (pieces & PST_E1_FREE) { if (int rc = half_step(true, false, e1, EA, HA, EA)) return rc; add(EA, s1); }
-    if ((pieces & PST_E1_GHOST) && lo_skip) { if (int rc = half_step(true, true, e1, EA, HA, EA)) return rc; add(EA, g1); }
-    if (pieces & PST_H1_FREE) if (int rc = half_step(false, false, h1, HA, EA, HA)) return rc;
-    if ((pieces & PST_H1_GHOST) && hi_skip) if (int rc = half_step(false, true, h1, HA, EA, HA)) return rc;
+    if (pieces & PST_E1_FREE) { if (int rc = half_step(true, false, e1, pb.hole4, EA, HA, EA)) return rc; add(EA, s1); }
+    if ((pieces & PST_E1_GHOST) && lo_skip) { if (int rc = half_step(true, true, e1, pb.hole4, EA, HA, EA)) return rc; add(EA, g1); }
+    if (pieces & PST_H1_FREE) if (int rc = half_step(false, false, h1, pb.hole3, HA, EA, HA)) return rc;
+    if ((pieces & PST_H1_GHOST) && hi_skip) if (int rc = half_step(false, true, h1, pb.hole3, HA, EA, HA)) return rc;
     // second step, from A into B
-    if (pieces & PST_E2_FREE) { if (int rc = half_step(true, false, m.box, EA, HA, EB)) return rc; add(EB, s2); }
-    if ((pieces & PST_E2_GHOST) && lo_skip) { if (int rc = half_step(true, true, m.box, EA, HA, EB)) return rc; add(EB, g2); }
-    if (pieces & PST_H2_FREE) if (int rc = half_step(false, false, m.box, HA, EB, HB)) return rc;
-    if ((pieces & PST_H2_GHOST) && hi_skip) if (int rc = half_step(false, true, m.box, HA, EB, HB)) return rc;
+    if (pieces & PST_E2_FREE) { if (int rc = half_step(true, false, m.box, pb.hole2, EA, HA, EB)) return rc; add(EB, s2); }
+    if ((pieces & PST_E2_GHOST) && lo_skip) { if (int rc = half_step(true, true, m.box, pb.hole2, EA, HA, EB)) return rc; add(EB, g2); }
+    if (pieces & PST_H2_FREE) if (int rc = half_step(false, false, m.box, pb.hole2, HA, EB, HB)) return rc;
+    if ((pieces & PST_H2_GHOST) && hi_skip) if (int rc = half_step(false, true, m.box, pb.hole2, HA, EB, HB)) return rc;
     HIPCHK(hipGetLastError());
   }
   if (pieces & PST_H2_GHOST) {
@@ -740,18 +774,20 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
 bool whole_pair_possible(const fdtdhip_plan* p, int32_t inner_out[6], bool staged) {
   const char* e = getenv("FDTDHIP_MARCH2");
   if (e && atoi(e) == 0) return false;
-  int inner[6], e1[6], h1[6];
+  PairBoxes pb;
+  const int (&inner)[6] = pb.inner;
   const bool halo = p->H_below || p->E_above;
-  if (!(p->objs.empty() && halo == staged && p->dets.empty() &&
+  if (!(halo == staged && p->dets.empty() &&
         p->trace_cursor < 0 && p->nz >= MARCH2_ZOWN && p->mat_const[0] && p->mat_const[1] &&
         (int64_t)p->ny * p->nz * 3 * (p->dtype == FDTDHIP_F32 ? 4 : 8) < (1ll << 32) &&   // in-plane byte offsets
-        pair_boxes(p, inner, e1, h1)))
+        pair_boxes(p, pb)))
     return false;
   // the marching kernels' other conditions and the size from which they pay, with the share of
   // the cells outside the inner box in place of the one-step march's shell: two steps per pass
   // pay up to a larger share (256^3 float64 with six ten-cell faces, 26 % outside the inner
   // box: 0.402 ms per step against 0.505 for half steps and 0.489 for the one-step march)
-  const int64_t in = (int64_t)(inner[1] - inner[0]) * (inner[3] - inner[2]) * (inner[5] - inner[4]);
+  const int64_t in = (int64_t)(inner[1] - inner[0]) * (inner[3] - inner[2]) * (inner[5] - inner[4]) -
+                     (int64_t)(pb.hole2[1] - pb.hole2[0]) * (pb.hole2[3] - pb.hole2[2]) * (pb.hole2[5] - pb.hole2[4]);
   if (fused_kind(p, staged, 1.0) != FUSED_MARCH) return false;
   if (fused_kind(p, staged, 0.0) != FUSED_MARCH &&      // (not forced by FDTDHIP_FUSED=2, not a whole grid)
       (double)(p->cells() - in) > MARCH2_OUTSIDE_SHARE * (double)p->cells())

@@ -59,6 +59,9 @@ struct March2Args {
                                    // two cells around the box on every side are read and, with
                                    // the cells of the box, evaluated as plain cells: they must
                                    // be inside the grid's faces or plain themselves
+  int hole[6];                     // a box inside `box` whose cells are not stored (objects and
+                                   // the two layers around them: evaluated as plain cells here,
+                                   // their results and what they taint stay in registers), or zeros
   int nsrc;                        // additive source points: cell, component, value per step
   int src_i[MAX_STEP_SOURCES], src_j[MAX_STEP_SOURCES], src_k[MAX_STEP_SOURCES], src_c[MAX_STEP_SOURCES];
   T src_v[2][MAX_STEP_SOURCES];
@@ -110,6 +113,7 @@ struct March2Wave {
   int j0, k, i0, i1;
   int by0, by1;              // rows of the box
   bool kown, hasz, hasz1;
+  bool zhole;                // the lane's cell lies in the z range of the hole
   unsigned koff, zoff;       // the lane's cell and its z neighbour within a row, in bytes (clamped)
   unsigned joff[NR];         // the rows within a plane, in elements (clamped)
   int64_t sx;                // elements per plane
@@ -130,6 +134,11 @@ __device__ __forceinline__ void march2_plane(const March2Args<T>& a, const March
   auto hasy = [&](int r) { return !EDGE || w.j0 - 2 + r > 0; };
   auto hasy1 = [&](int r) { return !EDGE || w.j0 - 2 + r < ny - 1; };
   auto inside = [&](int r) { return w.j0 - 2 + r < w.by1; };   // (owned rows start at the box's first)
+  // the lane's cell of row r of plane x lies in the hole (waves that meet the hole take the
+  // version with the tests)
+  auto holed = [&](int x, int r) {
+    return EDGE && w.zhole && x >= a.hole[0] && x < a.hole[1] && w.j0 - 2 + r >= a.hole[2] && w.j0 - 2 + r < a.hole[3];
+  };
   // ---- E' of plane i (a plane past the grid: clamped loads, nothing valid reads the result) ----
   {
     const int64_t pbase = (int64_t)min(i, nx - 1) * w.sx;
@@ -205,7 +214,7 @@ __device__ __forceinline__ void march2_plane(const March2Args<T>& a, const March
       T* ep = a.E1 + (int64_t)ih * w.sx;
 #pragma unroll
       for (int r = 2; r < TY + 2; ++r) {
-        if (!inside(r)) continue;
+        if (!inside(r) || holed(ih, r)) continue;
         T* o = at_bytes(ep + w.joff[r], w.koff);
         march2_store(E2c[r][0], o);
         march2_store(E2c[r][1], o + 1);
@@ -235,7 +244,7 @@ __device__ __forceinline__ void march2_plane(const March2Args<T>& a, const March
       T* hp = a.H1 + (int64_t)ig * w.sx;
 #pragma unroll
       for (int r = 2; r < TY + 2; ++r) {
-        if (!inside(r)) continue;
+        if (!inside(r) || holed(ig, r)) continue;
         T* o = at_bytes(hp + w.joff[r], w.koff);
         march2_store(h[r][0], o);
         march2_store(h[r][1], o + 1);
@@ -265,6 +274,7 @@ __global__ __launch_bounds__(64 * MARCH2_WAVES) __attribute__((amdgpu_waves_per_
   w.kown = w.k < a.box[5] && lane >= 1 && lane <= MARCH2_ZOWN;
   w.hasz = w.k > 0;
   w.hasz1 = w.k < nz - 1;
+  w.zhole = w.k >= a.hole[4] && w.k < a.hole[5];
   w.by0 = a.box[2];
   w.by1 = a.box[3];
   w.j0 = w.by0 + tile * TY;
@@ -282,6 +292,8 @@ __global__ __launch_bounds__(64 * MARCH2_WAVES) __attribute__((amdgpu_waves_per_
   // a wave takes the version with the tests unless each of its rows and the two above and below
   // lie inside the grid and no source point is among the cells it evaluates
   bool edge = w.j0 < 3 || w.j0 + TY + 2 >= ny;
+  // (the hole: rows and planes are tested per store; any lane in its z range will do here)
+  edge |= a.hole[1] > a.hole[0] && w.j0 < a.hole[3] && w.j0 + TY > a.hole[2] && __any(w.zhole);
 #pragma unroll
   for (int n = 0; n < MAX_STEP_SOURCES; ++n)
     edge |= n < a.nsrc && a.src_j[n] >= w.j0 - 2 && a.src_j[n] < w.j0 - 2 + NR &&
@@ -366,6 +378,11 @@ __device__ __forceinline__ void march2_row_plane(const March2Args<T>& a, const M
   auto hasy = [&](int r) { return !EDGE || w.j0 - 2 + r > 0; };
   auto hasy1 = [&](int r) { return !EDGE || w.j0 - 2 + r < ny - 1; };
   auto inside = [&](int r) { return w.j0 - 2 + r < w.by1; };   // (owned rows start at the box's first)
+  // the lane's cell of row r of plane x lies in the hole (waves that meet the hole take the
+  // version with the tests)
+  auto holed = [&](int x, int r) {
+    return EDGE && w.zhole && x >= a.hole[0] && x < a.hole[1] && w.j0 - 2 + r >= a.hole[2] && w.j0 - 2 + r < a.hole[3];
+  };
   // ---- E' of plane i ----------------------------------------------------------------------
   // (requesting the loads of plane i+1 here, to travel while the other stages are evaluated:
   // 512^3 float32 1.74 against 1.57 ms per launch -- the registers they occupy, not the wait
@@ -459,7 +476,7 @@ __device__ __forceinline__ void march2_row_plane(const March2Args<T>& a, const M
       T* ep = a.E1 + (int64_t)ie * w.sx;
 #pragma unroll
       for (int r = 2; r < TY + 2; ++r) {
-        if (!inside(r)) continue;
+        if (!inside(r) || holed(ie, r)) continue;
         T* o = at_bytes(ep + w.joff[r], w.koff);
         march2_store(E2c[r][0], o);
         march2_store(E2c[r][1], o + 1);
@@ -491,7 +508,7 @@ __device__ __forceinline__ void march2_row_plane(const March2Args<T>& a, const M
       T* hp = a.H1 + (int64_t)ig * w.sx;
 #pragma unroll
       for (int r = 2; r < TY + 2; ++r) {
-        if (!inside(r)) continue;
+        if (!inside(r) || holed(ig, r)) continue;
         T* o = at_bytes(hp + w.joff[r], w.koff);
         march2_store(h[r][0], o);
         march2_store(h[r][1], o + 1);
@@ -527,6 +544,7 @@ __global__ __launch_bounds__(64 * MW) void step_march2_rows(March2Args<T> a) {
   w.kown = w.k >= a.box[4] && w.k < a.box[5];
   w.hasz = w.k > 0;
   w.hasz1 = w.k < nz - 1;
+  w.zhole = w.k >= a.hole[4] && w.k < a.hole[5];
   w.by0 = a.box[2];
   w.by1 = a.box[3];
   w.j0 = w.by0 + tile * TY;
@@ -542,6 +560,8 @@ __global__ __launch_bounds__(64 * MW) void step_march2_rows(March2Args<T> a) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) { w.ce[c] = a.ce[c]; w.ch[c] = a.ch[c]; }
   bool edge = w.j0 < 3 || w.j0 + TY + 2 >= ny;
+  // (the hole: rows and planes are tested per store; any lane in its z range will do here)
+  edge |= a.hole[1] > a.hole[0] && w.j0 < a.hole[3] && w.j0 + TY > a.hole[2] && __any(w.zhole);
 #pragma unroll
   for (int n = 0; n < MAX_STEP_SOURCES; ++n)
     edge |= n < a.nsrc && a.src_j[n] >= w.j0 - 2 && a.src_j[n] < w.j0 - 2 + NR &&

@@ -213,14 +213,18 @@ _FACES = {
     # another order of the axes, unequal thicknesses, faces missing, one a single cell thick
     "four-faces": [(1, "high", 5), (0, "low", 9), (2, "low", 1), (2, "high", 11)],
     "x-faces": [(0, "low", 4), (0, "high", 6)],
+    "no-faces": [],
 }
 
 
-def _pml_case(dtype, shape, faces, steps, seed=0):
+def _pml_case(dtype, shape, faces, steps, seed=0, objects=False):
     """Two steps per pass on a plan with PML faces: the two-step kernel over the inner box, the
     cells around it by two steps of the shell kernels.  Bitwise equal to explicit half steps
     (fields and memory variables), the oracle within tolerance.  Sources in the faces, in every
-    layer between the faces and the inner box, and inside it."""
+    layer between the faces and the inner box, and inside it.  objects: an anisotropic box with
+    off-diagonal entries and an absorbing one that overlaps it inside the core, a plain one that
+    reaches into the low x face -- the box that holds them and the layers around it belong to
+    the cells that take the steps one after the other; sources next to it and inside it."""
     fdtd.set_backend(f"hip.{dtype}")
     nx, ny, nz = shape
     rs = np.random.RandomState(40 + seed)
@@ -233,10 +237,21 @@ def _pml_case(dtype, shape, faces, steps, seed=0):
     for layer in range(6):      # one source per layer inwards from the low faces
         sources.append(((min(lo[0] + layer, nx - 1), min(lo[1] + layer, ny - 1), min(lo[2] + layer, nz - 1)), 5 + layer))
     sources.append(((min(lo[0] + 3, nx - 1), ny // 2, nz // 2 + 1), 13))
+    off = 0.04 * np.random.RandomState(5).randn(8, 10, 30, 3, 3)
+    if objects:      # sources: under an object, and one to four cells beside the box of the objects
+        sources = sources[:3] + [((16, 20, 50), 6), ((29, 18, 60), 8), ((12, 12, 38), 5), ((31, 43 % ny, 92), 9),
+                                 ((30, 30, 91), 12)]
 
     def build():
         g = fdtd.Grid(shape, permittivity=1.3)
         g.E, g.H = fdtd.backend.array(E0), fdtd.backend.array(H0)
+        if objects:
+            ani = fdtd.AnisotropicObject(permittivity=1.8)
+            g[14:22, 16:26, 40:70] = ani
+            with torch.no_grad():
+                ani.inverse_permittivity += fdtd.backend.array(off)
+            g[20:28, 14:20, 60:90] = fdtd.AbsorbingObject(permittivity=1.5, conductivity=3e-3)
+            g[2:12, 30:40, 20:50] = fdtd.Object(permittivity=2.5)
         for axis, side, t in _FACES[faces]:
             loc = [slice(None)] * 3
             loc[axis] = slice(0, t) if side == "low" else slice(-t, None)
@@ -271,6 +286,11 @@ def _pml_case(dtype, shape, faces, steps, seed=0):
             assert torch.equal(po._psiE, pb._psiE) and torch.equal(po._psiH, pb._psiH), (shape, faces, what)
     o = orc.OracleGrid(shape, permittivity=1.3)
     o.E[...], o.H[...] = E0, H0
+    if objects:
+        oa = o.add_object((14, 22, 16, 26, 40, 70), 1.8, kind="anisotropic")
+        oa.inverse_permittivity += off
+        o.add_object((20, 28, 14, 20, 60, 90), 1.5, kind="absorbing", conductivity=3e-3)
+        o.add_object((2, 12, 30, 40, 20, 50), 2.5)
     for axis, side, t in _FACES[faces]:
         o.add_pml(axis, side, t)
     for cell, period in sources[:8]:
@@ -294,6 +314,10 @@ def test_two_steps_per_pass_with_pml_faces():
             "        for steps in (4, 9):\n"
             "            t._pml_case(dtype, shape, faces, steps, seed=n)\n"
             "            n += 1\n"
+            "for dtype, shape in (('float64', (40, 44, 130)), ('float32', (46, 50, 600))):\n"
+            "    for faces in ('six-faces', 'four-faces', 'no-faces'):\n"
+            "        t._pml_case(dtype, shape, faces, 9, seed=n, objects=True)\n"
+            "        n += 1\n"
             "print('two steps per pass with faces:', n, 'cases')\n")
     done = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FDTDHIP_FUSED="2"),
                           capture_output=True, text=True, timeout=280, cwd=here)
