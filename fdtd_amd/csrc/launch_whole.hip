@@ -204,8 +204,14 @@ int march_chunk_planes(int planes, int tiles, int slots, int extra) {
   for (int chunks = 1; chunks <= std::max(1, planes / 16); ++chunks) {
     const int lx = (planes + chunks - 1) / chunks;
     if (lx > 128) continue;
-    const int64_t wgs = (int64_t)tiles * ((planes + lx - 1) / lx);
-    const int64_t rounds = (wgs + slots - 1) / slots;
+    const int64_t nchunks = (planes + lx - 1) / lx;
+    const int64_t wgs = (int64_t)tiles * nchunks;
+    // with 16 tiles or more they are dealt to the XCDs in bands of ceil(tiles / 8), each XCD
+    // with an eighth of the places: the fullest XCD sets the number of rounds (82 tiles in
+    // bands of 11 and 6 chunks: 66 workgroups on 32 places, three rounds where the whole
+    // machine would count 1.92 -- the two-step kernel then took 1.78 instead of 1.43 ms)
+    const int64_t rounds = tiles >= 16 ? (((tiles + 7) / 8) * nchunks + slots / 8 - 1) / std::max(slots / 8, 1)
+                                       : (wgs + slots - 1) / slots;
     const double score = (double)wgs / (double)(rounds * slots) * lx / (lx + (double)extra) * (rounds >= 2 ? 1.0 : 0.97);
     if (score > best + 1e-9) { best = score; best_lx = lx; }
   }
@@ -666,6 +672,22 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
     m.src_i[n] = m.src_j[n] = m.src_k[n] = m.src_c[n] = -1;
     m.src_v[0][n] = m.src_v[1][n] = T(0);
   }
+  // detectors: the first step's readings of the cells the two-step kernel stores are evaluated
+  // once more by a kernel of their own, from the state before the pair (yee_march2.hpp)
+  March2Dets<T> dets;
+  dets.count = 0;
+  dets.first[0] = 0;
+  for (const DetH& d : p->dets) {
+    if (d.kind != FDTDHIP_DET_CELLS || d.n == 0) continue;
+    if (dets.count >= MARCH2_MAX_DETS) return fail(-1, "internal: more detectors than two steps per pass serve");
+    if (!d.outE || !d.outH || d.usedE + 2 > d.capacity || d.usedH + 2 > d.capacity)
+      return fail(-3, "detector output capacity exhausted");
+    dets.cell[dets.count] = d.cell;
+    dets.outE[dets.count] = (T*)d.outE + d.usedE * d.n * 3;
+    dets.outH[dets.count] = (T*)d.outH + d.usedH * d.n * 3;
+    dets.first[dets.count + 1] = dets.first[dets.count] + d.n;
+    ++dets.count;
+  }
   // z rows of up to 512 cells: a workgroup of up to eight waves per tile, which hand each other
   // what crosses their ends through LDS (step_march2_rows); longer rows: independent waves
   // (step_march2).  FDTDHIP_MARCH2_ROWS=0 in the environment: independent waves always (tests).
@@ -709,6 +731,11 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
     hipLaunchKernelGGL(kernel, grid, block, 0, p->stream, m);
     HIPCHK(hipGetLastError());
     if (int rc = span_end(p, slot, TIME_PAIR)) return rc;
+    if (dets.count > 0) {
+      hipLaunchKernelGGL((march2_detect_first_step<T>), dim3(blocks_for(dets.first[dets.count])), dim3(256), 0,
+                         p->stream, m, dets);
+      HIPCHK(hipGetLastError());
+    }
   }
   if (shell) {
     T* EA = (T*)p->E; T* HA = (T*)p->H; T* EB = (T*)p->E_alt; T* HB = (T*)p->H_alt;
@@ -748,6 +775,27 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
     if ((pieces & PST_E1_GHOST) && lo_skip) { if (int rc = half_step(true, true, e1, pb.hole4, EA, HA, EA)) return rc; add(EA, g1); }
     if (pieces & PST_H1_FREE) if (int rc = half_step(false, false, h1, pb.hole3, HA, EA, HA)) return rc;
     if ((pieces & PST_H1_GHOST) && hi_skip) if (int rc = half_step(false, true, h1, pb.hole3, HA, EA, HA)) return rc;
+    if ((pieces & PST_H1_GHOST) && dets.count > 0) {
+      // the first step's readings of the other cells: from A, which holds their state after it
+      DetRegion reg;
+      reg.ny = p->ny; reg.nz = p->nz;
+      for (int n = 0; n < 6; ++n) { reg.inner[n] = m.box[n]; reg.hole[n] = m.hole[n]; }
+      for (int phase = 0; phase < 2; ++phase) {
+        DetBatch<T> batch;
+        batch.count = 0;
+        batch.first[0] = 0;
+        for (const DetH& d : p->dets) {
+          if (d.kind != FDTDHIP_DET_CELLS || d.n == 0) continue;
+          batch.cell[batch.count] = d.cell;
+          batch.out[batch.count] = phase == 0 ? (T*)d.outE + d.usedE * d.n * 3 : (T*)d.outH + d.usedH * d.n * 3;
+          batch.first[batch.count + 1] = batch.first[batch.count] + d.n * 3;
+          ++batch.count;
+        }
+        hipLaunchKernelGGL((detect_cells_batch_outside<T>), dim3(blocks_for(batch.first[batch.count])), dim3(256), 0,
+                           p->stream, phase == 0 ? (const T*)EA : (const T*)HA, batch, reg);
+      }
+      HIPCHK(hipGetLastError());
+    }
     // second step, from A into B
     if (pieces & PST_E2_FREE) { if (int rc = half_step(true, false, m.box, pb.hole2, EA, HA, EB)) return rc; add(EB, s2); }
     if ((pieces & PST_E2_GHOST) && lo_skip) { if (int rc = half_step(true, true, m.box, pb.hole2, EA, HA, EB)) return rc; add(EB, g2); }
@@ -755,10 +803,17 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
     if ((pieces & PST_H2_GHOST) && hi_skip) if (int rc = half_step(false, true, m.box, pb.hole2, HA, EB, HB)) return rc;
     HIPCHK(hipGetLastError());
   }
+  if ((pieces & PST_H1_GHOST) && !p->dets.empty())
+    for (DetH& d : p->dets)
+      if (d.kind == FDTDHIP_DET_CELLS) { ++d.usedE; ++d.usedH; }      // the first step's record row
   if (pieces & PST_H2_GHOST) {
     std::swap(p->E, p->E_alt);
     std::swap(p->H, p->H_alt);
     p->step_flipped = !p->step_flipped;
+    if (!p->dets.empty()) {      // the second step's readings: every cell's state is in memory
+      if (int rc = half_post(p, true, q + 1, POST_FINISH)) return rc;
+      if (int rc = half_post(p, false, q + 1, POST_FINISH)) return rc;
+    }
   }
   return 0;
 }
@@ -777,7 +832,12 @@ bool whole_pair_possible(const fdtdhip_plan* p, int32_t inner_out[6], bool stage
   PairBoxes pb;
   const int (&inner)[6] = pb.inner;
   const bool halo = p->H_below || p->E_above;
-  if (!(halo == staged && p->dets.empty() &&
+  int served = 0;
+  for (const DetH& d : p->dets) {      // detectors: cell lists, a few
+    if (d.kind != FDTDHIP_DET_CELLS) return false;
+    if (d.n > 0 && ++served > MARCH2_MAX_DETS) return false;
+  }
+  if (!(halo == staged &&
         p->trace_cursor < 0 && p->nz >= MARCH2_ZOWN && p->mat_const[0] && p->mat_const[1] &&
         (int64_t)p->ny * p->nz * 3 * (p->dtype == FDTDHIP_F32 ? 4 : 8) < (1ll << 32) &&   // in-plane byte offsets
         pair_boxes(p, pb)))

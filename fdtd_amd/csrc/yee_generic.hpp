@@ -508,6 +508,27 @@ __global__ void detect_cells_batch(const T* F, DetBatch<T> b) {
     }
 }
 
+// The same, leaving out the cells inside `inner` and outside `hole`: a two-step kernel has
+// written their readings itself (yee_march2.hpp).
+struct DetRegion { int ny, nz; int inner[6]; int hole[6]; };
+template <typename T>
+__global__ void detect_cells_batch_outside(const T* F, DetBatch<T> b, DetRegion g) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= b.first[b.count]) return;
+#pragma unroll
+  for (int d = 0; d < MAX_DET_BATCH; ++d)
+    if (d < b.count && t >= b.first[d] && t < b.first[d + 1]) {
+      const int64_t u = t - b.first[d];
+      const int64_t cell = b.cell[d][u / 3], plane = (int64_t)g.ny * g.nz;
+      const int i = (int)(cell / plane), j = (int)((cell % plane) / g.nz), k = (int)(cell % g.nz);
+      const bool in = i >= g.inner[0] && i < g.inner[1] && j >= g.inner[2] && j < g.inner[3] &&
+                      k >= g.inner[4] && k < g.inner[5];
+      const bool holed = i >= g.hole[0] && i < g.hole[1] && j >= g.hole[2] && j < g.hole[3] &&
+                         k >= g.hole[4] && k < g.hole[5];
+      if (!in || holed) b.out[d][u] = F[cell * 3 + (u % 3)];
+    }
+}
+
 // Loop-current detector (reference fdtd/detectors.py:443-462), including the
 // carry of the first layer's Hy term into the second layer (line 456) and
 // Python's wrap-around for index -1.

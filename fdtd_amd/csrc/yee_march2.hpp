@@ -59,9 +59,14 @@ struct March2Args {
                                    // two cells around the box on every side are read and, with
                                    // the cells of the box, evaluated as plain cells: they must
                                    // be inside the grid's faces or plain themselves
-  int hole[6];                     // a box inside `box` whose cells are not stored (objects and
-                                   // the two layers around them: evaluated as plain cells here,
-                                   // their results and what they taint stay in registers), or zeros
+  int hole[6];                     // a box inside `box` (objects and the two layers around them),
+                                   // or zeros.  The march evaluates its cells as the plain cells
+                                   // they are not and stores the results like any others: the
+                                   // launches that take those cells' two steps one after the
+                                   // other overwrite them afterwards, and nothing valid depends
+                                   // on them (a per-lane test in the stores instead cost 4.5 %:
+                                   // the waves that carry tests pace their workgroups).  Only the
+                                   // detector kernel below consults it
   int nsrc;                        // additive source points: cell, component, value per step
   int src_i[MAX_STEP_SOURCES], src_j[MAX_STEP_SOURCES], src_k[MAX_STEP_SOURCES], src_c[MAX_STEP_SOURCES];
   T src_v[2][MAX_STEP_SOURCES];
@@ -113,7 +118,6 @@ struct March2Wave {
   int j0, k, i0, i1;
   int by0, by1;              // rows of the box
   bool kown, hasz, hasz1;
-  bool zhole;                // the lane's cell lies in the z range of the hole
   unsigned koff, zoff;       // the lane's cell and its z neighbour within a row, in bytes (clamped)
   unsigned joff[NR];         // the rows within a plane, in elements (clamped)
   int64_t sx;                // elements per plane
@@ -134,11 +138,6 @@ __device__ __forceinline__ void march2_plane(const March2Args<T>& a, const March
   auto hasy = [&](int r) { return !EDGE || w.j0 - 2 + r > 0; };
   auto hasy1 = [&](int r) { return !EDGE || w.j0 - 2 + r < ny - 1; };
   auto inside = [&](int r) { return w.j0 - 2 + r < w.by1; };   // (owned rows start at the box's first)
-  // the lane's cell of row r of plane x lies in the hole (waves that meet the hole take the
-  // version with the tests)
-  auto holed = [&](int x, int r) {
-    return EDGE && w.zhole && x >= a.hole[0] && x < a.hole[1] && w.j0 - 2 + r >= a.hole[2] && w.j0 - 2 + r < a.hole[3];
-  };
   // ---- E' of plane i (a plane past the grid: clamped loads, nothing valid reads the result) ----
   {
     const int64_t pbase = (int64_t)min(i, nx - 1) * w.sx;
@@ -214,7 +213,7 @@ __device__ __forceinline__ void march2_plane(const March2Args<T>& a, const March
       T* ep = a.E1 + (int64_t)ih * w.sx;
 #pragma unroll
       for (int r = 2; r < TY + 2; ++r) {
-        if (!inside(r) || holed(ih, r)) continue;
+        if (!inside(r)) continue;
         T* o = at_bytes(ep + w.joff[r], w.koff);
         march2_store(E2c[r][0], o);
         march2_store(E2c[r][1], o + 1);
@@ -244,7 +243,7 @@ __device__ __forceinline__ void march2_plane(const March2Args<T>& a, const March
       T* hp = a.H1 + (int64_t)ig * w.sx;
 #pragma unroll
       for (int r = 2; r < TY + 2; ++r) {
-        if (!inside(r) || holed(ig, r)) continue;
+        if (!inside(r)) continue;
         T* o = at_bytes(hp + w.joff[r], w.koff);
         march2_store(h[r][0], o);
         march2_store(h[r][1], o + 1);
@@ -274,7 +273,6 @@ __global__ __launch_bounds__(64 * MARCH2_WAVES) __attribute__((amdgpu_waves_per_
   w.kown = w.k < a.box[5] && lane >= 1 && lane <= MARCH2_ZOWN;
   w.hasz = w.k > 0;
   w.hasz1 = w.k < nz - 1;
-  w.zhole = w.k >= a.hole[4] && w.k < a.hole[5];
   w.by0 = a.box[2];
   w.by1 = a.box[3];
   w.j0 = w.by0 + tile * TY;
@@ -293,7 +291,6 @@ __global__ __launch_bounds__(64 * MARCH2_WAVES) __attribute__((amdgpu_waves_per_
   // lie inside the grid and no source point is among the cells it evaluates
   bool edge = w.j0 < 3 || w.j0 + TY + 2 >= ny;
   // (the hole: rows and planes are tested per store; any lane in its z range will do here)
-  edge |= a.hole[1] > a.hole[0] && w.j0 < a.hole[3] && w.j0 + TY > a.hole[2] && __any(w.zhole);
 #pragma unroll
   for (int n = 0; n < MAX_STEP_SOURCES; ++n)
     edge |= n < a.nsrc && a.src_j[n] >= w.j0 - 2 && a.src_j[n] < w.j0 - 2 + NR &&
@@ -378,11 +375,6 @@ __device__ __forceinline__ void march2_row_plane(const March2Args<T>& a, const M
   auto hasy = [&](int r) { return !EDGE || w.j0 - 2 + r > 0; };
   auto hasy1 = [&](int r) { return !EDGE || w.j0 - 2 + r < ny - 1; };
   auto inside = [&](int r) { return w.j0 - 2 + r < w.by1; };   // (owned rows start at the box's first)
-  // the lane's cell of row r of plane x lies in the hole (waves that meet the hole take the
-  // version with the tests)
-  auto holed = [&](int x, int r) {
-    return EDGE && w.zhole && x >= a.hole[0] && x < a.hole[1] && w.j0 - 2 + r >= a.hole[2] && w.j0 - 2 + r < a.hole[3];
-  };
   // ---- E' of plane i ----------------------------------------------------------------------
   // (requesting the loads of plane i+1 here, to travel while the other stages are evaluated:
   // 512^3 float32 1.74 against 1.57 ms per launch -- the registers they occupy, not the wait
@@ -476,7 +468,7 @@ __device__ __forceinline__ void march2_row_plane(const March2Args<T>& a, const M
       T* ep = a.E1 + (int64_t)ie * w.sx;
 #pragma unroll
       for (int r = 2; r < TY + 2; ++r) {
-        if (!inside(r) || holed(ie, r)) continue;
+        if (!inside(r)) continue;
         T* o = at_bytes(ep + w.joff[r], w.koff);
         march2_store(E2c[r][0], o);
         march2_store(E2c[r][1], o + 1);
@@ -508,7 +500,7 @@ __device__ __forceinline__ void march2_row_plane(const March2Args<T>& a, const M
       T* hp = a.H1 + (int64_t)ig * w.sx;
 #pragma unroll
       for (int r = 2; r < TY + 2; ++r) {
-        if (!inside(r) || holed(ig, r)) continue;
+        if (!inside(r)) continue;
         T* o = at_bytes(hp + w.joff[r], w.koff);
         march2_store(h[r][0], o);
         march2_store(h[r][1], o + 1);
@@ -544,7 +536,6 @@ __global__ __launch_bounds__(64 * MW) void step_march2_rows(March2Args<T> a) {
   w.kown = w.k >= a.box[4] && w.k < a.box[5];
   w.hasz = w.k > 0;
   w.hasz1 = w.k < nz - 1;
-  w.zhole = w.k >= a.hole[4] && w.k < a.hole[5];
   w.by0 = a.box[2];
   w.by1 = a.box[3];
   w.j0 = w.by0 + tile * TY;
@@ -561,7 +552,6 @@ __global__ __launch_bounds__(64 * MW) void step_march2_rows(March2Args<T> a) {
   for (int c = 0; c < 3; ++c) { w.ce[c] = a.ce[c]; w.ch[c] = a.ch[c]; }
   bool edge = w.j0 < 3 || w.j0 + TY + 2 >= ny;
   // (the hole: rows and planes are tested per store; any lane in its z range will do here)
-  edge |= a.hole[1] > a.hole[0] && w.j0 < a.hole[3] && w.j0 + TY > a.hole[2] && __any(w.zhole);
 #pragma unroll
   for (int n = 0; n < MAX_STEP_SOURCES; ++n)
     edge |= n < a.nsrc && a.src_j[n] >= w.j0 - 2 && a.src_j[n] < w.j0 - 2 + NR &&
@@ -589,6 +579,82 @@ __global__ __launch_bounds__(64 * MW) void step_march2_rows(March2Args<T> a) {
   } else {
     for (int i = is; i <= iend; ++i) march2_row_plane<T, TY, MW, false>(a, w, x, wave, lane, i, Hp, E1a, E1b, H1a, H1b, E2a);
   }
+}
+
+
+// ---- detectors ----------------------------------------------------------------------------
+// A detector reads E after the sources and H after the H half step of EVERY step (reference
+// fdtd/detectors.py:114-124).  For the cells the two-step kernels store, the state after the
+// first step of a pair exists in registers only; this kernel evaluates it once more for the few
+// cells a detector reads -- plain cells with plain neighbours, from the state before the pair:
+// the cell's E', and for its H' the E' of the three cells after it as well.  Same operations on
+// the same operands as the owner's.  One lane per detector cell; the cells outside `box` or inside
+// `hole` are left to the ordinary detector kernel, which reads them after the first step.
+
+// E after the first step (sources included) of the plain cell (i, j, k).
+template <typename T>
+__device__ __forceinline__ void march2_plain_E1(const March2Args<T>& a, int i, int j, int k, T e[3]) {
+  const int64_t sy = 3 * (int64_t)a.nz, sx = sy * a.ny;
+  const int64_t c3 = (int64_t)i * sx + (int64_t)j * sy + 3 * k;
+  const T* h = a.H0 + c3;
+  const T* hx = i > 0 ? h - sx : h;
+  const T* hy = j > 0 ? h - sy : h;
+  const T* hz = k > 0 ? h - 3 : h;
+  const T x_y = i > 0 ? h[1] - hx[1] : T(0), x_z = i > 0 ? h[2] - hx[2] : T(0);
+  const T y_x = j > 0 ? h[0] - hy[0] : T(0), y_z = j > 0 ? h[2] - hy[2] : T(0);
+  const T z_x = k > 0 ? h[0] - hz[0] : T(0), z_y = k > 0 ? h[1] - hz[1] : T(0);
+  e[0] = a.E0[c3] + a.ce[0] * (y_z - z_y);
+  e[1] = a.E0[c3 + 1] + a.ce[1] * (z_x - x_z);
+  e[2] = a.E0[c3 + 2] + a.ce[2] * (x_y - y_x);
+#pragma unroll
+  for (int n = 0; n < MAX_STEP_SOURCES; ++n)
+    if (n < a.nsrc && a.src_i[n] == i && a.src_j[n] == j && a.src_k[n] == k) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) e[c] = a.src_c[n] == c ? e[c] + a.src_v[0][n] : e[c];
+    }
+}
+
+constexpr int MARCH2_MAX_DETS = 8;
+template <typename T>
+struct March2Dets {
+  int count;
+  const int64_t* cell[MARCH2_MAX_DETS];   // flat cell indices of each detector
+  T* outE[MARCH2_MAX_DETS];               // its record rows of the first step
+  T* outH[MARCH2_MAX_DETS];
+  int64_t first[MARCH2_MAX_DETS + 1];     // in cells
+};
+
+template <typename T>
+__global__ void march2_detect_first_step(March2Args<T> a, March2Dets<T> b) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= b.first[b.count]) return;
+#pragma unroll
+  for (int d = 0; d < MARCH2_MAX_DETS; ++d)
+    if (d < b.count && t >= b.first[d] && t < b.first[d + 1]) {
+      const int64_t u = t - b.first[d];
+      const int64_t cell = b.cell[d][u], plane = (int64_t)a.ny * a.nz;
+      const int i = (int)(cell / plane), j = (int)((cell % plane) / a.nz), k = (int)(cell % a.nz);
+      const bool in = i >= a.box[0] && i < a.box[1] && j >= a.box[2] && j < a.box[3] && k >= a.box[4] && k < a.box[5];
+      const bool holed = i >= a.hole[0] && i < a.hole[1] && j >= a.hole[2] && j < a.hole[3] &&
+                         k >= a.hole[4] && k < a.hole[5];
+      if (!in || holed) continue;
+      T e[3], ex[3] = {T(0), T(0), T(0)}, ey[3] = {T(0), T(0), T(0)}, ez[3] = {T(0), T(0), T(0)};
+      march2_plain_E1<T>(a, i, j, k, e);
+      const bool ox = i < a.nx - 1, oy = j < a.ny - 1, oz = k < a.nz - 1;
+      if (ox) march2_plain_E1<T>(a, i + 1, j, k, ex);
+      if (oy) march2_plain_E1<T>(a, i, j + 1, k, ey);
+      if (oz) march2_plain_E1<T>(a, i, j, k + 1, ez);
+      const T x_y = ox ? ex[1] - e[1] : T(0), x_z = ox ? ex[2] - e[2] : T(0);
+      const T y_x = oy ? ey[0] - e[0] : T(0), y_z = oy ? ey[2] - e[2] : T(0);
+      const T z_x = oz ? ez[0] - e[0] : T(0), z_y = oz ? ez[1] - e[1] : T(0);
+      const T* h0 = a.H0 + cell * 3;
+      T* oe = b.outE[d] + u * 3;
+      T* oh = b.outH[d] + u * 3;
+      oe[0] = e[0]; oe[1] = e[1]; oe[2] = e[2];
+      oh[0] = h0[0] - a.ch[0] * (y_z - z_y);
+      oh[1] = h0[1] - a.ch[1] * (z_x - x_z);
+      oh[2] = h0[2] - a.ch[2] * (x_y - y_x);
+    }
 }
 
 }  // namespace fdtdhip

@@ -444,12 +444,22 @@ def _march_case(dtype, shape, objects, faces="no-pml"):
         return g, det, off
 
     import ctypes
+    import os
 
     a, da, off = build()
     a._provide_step_buffers()
     lib = a._ensure_plan()
     _lib.check(lib.fdtdhip_plan_enable_timing(a._plan, 1))
-    a.run(steps, progress_bar=False)
+    # (one step per pass: this case is about the one-step marching kernel; the switch is read per call)
+    before = os.environ.get("FDTDHIP_MARCH2")
+    os.environ["FDTDHIP_MARCH2"] = "0"
+    try:
+        a.run(steps, progress_bar=False)
+    finally:
+        if before is None:
+            del os.environ["FDTDHIP_MARCH2"]
+        else:
+            os.environ["FDTDHIP_MARCH2"] = before
     msE, nE, msH, nH = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
     _lib.check(lib.fdtdhip_plan_get_timing(a._plan, ctypes.byref(msE), ctypes.byref(nE),
                                             ctypes.byref(msH), ctypes.byref(nH)))

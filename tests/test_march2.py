@@ -117,23 +117,52 @@ def test_two_steps_per_launch_equal_half_steps_bitwise(dtype, shape, steps, dens
     assert rel_l2(host(a.E), o.E) <= TOL[dtype] and rel_l2(host(a.H), o.H) <= TOL[dtype]
 
 
-def test_detectors_and_recorded_runs_keep_one_step_per_launch():
-    """A detector has to read every step's fields, a recorded run every step's curl: such plans
-    stay with the one-step kernels."""
+def test_detectors_read_every_step_of_a_pair():
+    """A detector reads E after the sources and H after the H half step of every step
+    (reference fdtd/detectors.py:114-124).  With two steps per pass the state after the first
+    step of a pair never exists in memory: a small kernel evaluates it once more for the cells
+    the detectors read.  Lines along the three axes, a slanted line, a block, a line through a
+    source cell, on a vacuum grid of the benchmark's kind: records equal to those of explicit
+    half steps bit for bit."""
     fdtd.set_backend("hip.float32")
-    shape = (64, 128, 512)
-    g = fdtd.Grid(shape)
-    g[32, 64, 256] = fdtd.PointSource(period=9)
-    det = fdtd.LineDetector()
-    g[10:50, 64, 200] = det
-    g._provide_step_buffers()
-    lib = g._ensure_plan()
-    _lib.check(lib.fdtdhip_plan_enable_timing(g._plan, 1))
-    g.run(8, progress_bar=False)
-    pairs, singles, _ = _pair_launches(g, lib)
-    _lib.check(lib.fdtdhip_plan_enable_timing(g._plan, 0))
-    assert pairs == 0 and singles == 8
-    assert len(det.E) == 8
+    shape, steps = (64, 128, 512), 10
+    rs = np.random.RandomState(3)
+    E0, H0 = 1e-2 * rs.randn(*shape, 3), 1e-2 * rs.randn(*shape, 3)
+
+    def build():
+        g = fdtd.Grid(shape)
+        g.E, g.H = fdtd.backend.array(E0), fdtd.backend.array(H0)
+        g[32, 64, 256] = fdtd.PointSource(period=9)
+        g[0, 0, 0] = fdtd.PointSource(period=7)
+        dets = [fdtd.LineDetector() for _ in range(5)] + [fdtd.BlockDetector()]
+        g[0:64, 64, 200] = dets[0]
+        g[10, 0:128, 61] = dets[1]
+        g[63, 127, 0:512] = dets[2]
+        g[5:60, 10:120, 300] = dets[3]          # a slanted line
+        g[32, 64, 250:260] = dets[4]            # through the source cell
+        g[30:34, 62:66, 254:258] = dets[5]
+        return g, dets
+
+    a, da = build()
+    a._provide_step_buffers()
+    lib = a._ensure_plan()
+    _lib.check(lib.fdtdhip_plan_enable_timing(a._plan, 1))
+    a.run(steps, progress_bar=False)
+    pairs, singles, _ = _pair_launches(a, lib)
+    _lib.check(lib.fdtdhip_plan_enable_timing(a._plan, 0))
+    assert pairs == 4 and singles == 2
+    b, db = build()
+    for _ in range(steps):
+        b.update_E()
+        b.update_H()
+        b.time_steps_passed += 1
+    torch.cuda.synchronize()
+    assert torch.equal(a.E, b.E) and torch.equal(a.H, b.H)
+    for n, (x, y) in enumerate(zip(da, db)):
+        assert len(x.E) == len(x.H) == steps
+        assert torch.equal(torch.stack(list(x.E)), torch.stack(list(y.E))), n
+        assert torch.equal(torch.stack(list(x.H)), torch.stack(list(y.H))), n
+        assert float(torch.stack(list(x.H)).abs().max()) > 0
 
 
 def _small_case(seed):
@@ -258,6 +287,11 @@ def _pml_case(dtype, shape, faces, steps, seed=0, objects=False):
             g[tuple(loc)] = fdtd.PML()
         for cell, period in sources[:8]:
             g[cell] = fdtd.PointSource(period=period)
+        # detectors through faces, layers, inner box and (with objects) the box of the objects
+        g.dets = [fdtd.LineDetector(), fdtd.LineDetector(), fdtd.BlockDetector()]
+        g[0:nx, ny // 2, nz // 2 + 1] = g.dets[0]
+        g[16, 20, 0:nz] = g.dets[1]
+        g[10:24, 12:22, 45:48] = g.dets[2]
         return g
 
     a = build()
@@ -284,6 +318,9 @@ def _pml_case(dtype, shape, faces, steps, seed=0, objects=False):
         assert torch.equal(other.E, b.E) and torch.equal(other.H, b.H), (dtype, shape, faces, steps, what)
         for po, pb in zip(other.boundaries, b.boundaries):
             assert torch.equal(po._psiE, pb._psiE) and torch.equal(po._psiH, pb._psiH), (shape, faces, what)
+        for n, (do, dbb) in enumerate(zip(other.dets, b.dets)):
+            assert torch.equal(torch.stack(list(do.E)), torch.stack(list(dbb.E))), (shape, faces, what, "detector E", n)
+            assert torch.equal(torch.stack(list(do.H)), torch.stack(list(dbb.H))), (shape, faces, what, "detector H", n)
     o = orc.OracleGrid(shape, permittivity=1.3)
     o.E[...], o.H[...] = E0, H0
     if objects:
