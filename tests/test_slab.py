@@ -561,7 +561,9 @@ def test_large_slabs_take_whole_steps_by_default_and_equal_half_steps_bitwise(tm
         mp.spawn(_large_slab_worker, args=(3, slab_support.free_port(), out), nprocs=3, join=True)
         runs[mode] = np.load(out)
     assert list(runs["default"]["whole"]) == [6, 6, 6] and list(runs["0"]["whole"]) == [0, 0, 0]
-    for name in ("E", "H", "det"):
+    # (four of the six in two passes of two steps each: the object and the detector's cells allow it)
+    assert list(runs["default"]["pairs"]) == [4, 4, 4] and list(runs["0"]["pairs"]) == [0, 0, 0]
+    for name in ("E", "H", "det", "psi"):
         assert np.array_equal(runs["default"][name], runs["0"][name]), name
     assert np.abs(runs["default"]["E"]).max() > 0
 

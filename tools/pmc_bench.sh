@@ -19,13 +19,18 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        name = next((n for n in ("bulk_E", "bulk_H", "step_march_box", "step_march", "step_fused", "shell_E", "shell_H")
+        name = next((n for n in ("bulk_E", "bulk_H", "step_march2_rows", "step_march2", "march2_detect_first_step",
+                               "step_march_box", "step_march", "step_fused", "shell_E", "shell_H",
+                               "detect_cells_batch_outside")
                      if "fdtdhip::" + n in k), None)
         if name is None: continue
         agg[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 tot = {}
-# the dominant kernels: the whole-step kernel where the run took it, else the two bulk kernels
-whole = [n for n in ("step_march_box", "step_march", "step_fused") if n in agg]
+# the dominant kernels: the two-step kernel where the run took it (bytes per launch of two steps;
+# with --steps 12 --warmup 4 the later half of the shell launches all belong to pairs of steps,
+# two launches of shell_E and two of shell_H per pair), else the whole-step kernel, else the
+# two bulk kernels
+whole = [n for n in ("step_march2_rows", "step_march2", "step_march_box", "step_march", "step_fused") if n in agg]
 dominant = whole[:1] or ["bulk_E", "bulk_H"]
 for name in sorted(agg):
     for c, v in sorted(agg[name].items()):
