@@ -258,18 +258,19 @@ int fdtdhip_update_H_post_stage(fdtdhip_plan* plan, int64_t q, int stage);
  * boundary, no plane source, no halo), fdtdhip_run advances pairs of steps with one
  * kernel per step, first -> second buffers and back; after the call the state is
  * in the first buffers again.  Contents of the second buffers are scratch.
- * Large 3-D plans whose steps have nothing between them but additive source points
- * (no object, detector, recorded curl; both material arrays proven constant by
- * fdtdhip_plan_scan_materials) advance TWO steps per pass over memory, in groups of four
- * steps: the state after the odd steps of a group then never exists in memory (with PML
- * faces: only for the cells of the faces and the few layers next to them, which take the two
- * steps one after the other).  The result is the one of the half steps either way, bit for
- * bit. */
+ * Large 3-D plans with both material arrays proven constant by fdtdhip_plan_scan_materials,
+ * no recorded curl, at most eight additive source points and at most eight detectors, all
+ * of the cell kind, advance TWO steps per pass over memory, in groups of four steps: the
+ * state after the odd steps of a group then never exists in memory, except for the cells of
+ * PML faces and of the box that holds the objects and the few layers next to them, which
+ * take the two steps one after the other.  Detector readings of every step are delivered
+ * as by half steps.  The result is the one of the half steps either way, bit for bit. */
 int fdtdhip_plan_set_step_buffers(fdtdhip_plan* plan, void* E_alt, void* H_alt);
 /* Whether fdtdhip_run would advance this plan two steps per pass (1) or not (0), and the box
  * {x0,x1,y0,y1,z0,z1} the two-step kernel covers (inner, may be NULL): the whole grid, or with
  * PML faces the PML-free box shrunk by two cells on every side with a face; the cells outside it
- * take the two steps one after the other (no reference counterpart; benchmarks use it to
+ * (and those of the objects' box grown by two layers, which lies inside it) take the two steps
+ * one after the other (no reference counterpart; benchmarks use it to
  * price the kernels). */
 int fdtdhip_plan_two_step_box(fdtdhip_plan* plan, int staged, int32_t inner[6]);
 /* A pair of steps (time indices q, q + 1) of an x-slab in eight pieces around its four plane
