@@ -33,6 +33,7 @@ PROTOTYPES = {
     "fdtdhip_plan_set_fields": (_i, [_p, _p, _p, _p, _p]),
     "fdtdhip_plan_scan_materials": (_i, [_p, _i]),
     "fdtdhip_plan_set_halo": (_i, [_p, _p, _p]),
+    "fdtdhip_plan_bind": (_i, [_p] * 10),
     "fdtdhip_plan_set_step_buffers": (_i, [_p, _p, _p]),
     "fdtdhip_plan_set_pml_step_buffer": (_i, [_p, _i, _p]),
     "fdtdhip_plan_add_pml": (_i, [_p, _i, _i, _i, _pd, _pd, _pd, _pd, _p, _p]),
@@ -65,6 +66,7 @@ PROTOTYPES = {
     "fdtdhip_step_stage": (_i, [_p, _i64, _i]),
     "fdtdhip_step_into": (_i, [_p, _i64]),
     "fdtdhip_plan_two_step_box": (_i, [_p, _i, C.POINTER(C.c_int32)]),
+    "fdtdhip_two_step_launches": (C.c_int64, []),
     "fdtdhip_pair_stage": (_i, [_p, _i64, _i]),
     "fdtdhip_plan_set_object_trace": (_i, [_p, _i, _p, _i64]),
     "fdtdhip_plan_set_object_grad": (_i, [_p, _i, _p]),

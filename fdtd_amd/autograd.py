@@ -82,9 +82,7 @@ class _Run(torch.autograd.Function):
     def forward(ctx, grid, n, E, H, *rest):
         half, n = (None, n) if n > 0 else ("E" if n == -1 else "H", 1)
         ctx.half = half
-        objs, pmls = _learnable(grid), _active_pmls(grid)
-        mods = _modulated(objs)
-        srcs = _modulated_sources(grid)   # native ids known: the caller prepared the plan
+        objs, pmls, mods, srcs = grid._tape_lists   # (differentiable_advance made them)
         # object tensors, (weight, bias) per modulated object, (P, osc, weight, bias) per source
         k = len(objs) + 2 * len(mods) + 4 * len(srcs)
         src_in = rest[len(objs) + 2 * len(mods):k]
@@ -98,12 +96,12 @@ class _Run(torch.autograd.Function):
             p._psiE, p._psiH = psis[2 * n_p], psis[2 * n_p + 1]
         into = None
         if half is None and n == 1 and grid._single_steps_out_of_place():
-            grid.E, grid.H = E.detach(), H.detach()
-            if grid.E.is_contiguous() and grid.H.is_contiguous() and grid.E.dtype == bd.float == grid.H.dtype:
-                into = grid._step_buffers = (torch.empty_like(grid.E), torch.empty_like(grid.H))
-                for p in pmls:
-                    if getattr(p, "_psiE_alt", None) is None:
-                        p._psiE_alt = torch.empty_like(p._psiE)
+            # (the caller validated E and H: their detached aliases need no second look)
+            grid._bind_state(E.detach(), H.detach())
+            into = grid._step_buffers = (torch.empty_like(grid.E), torch.empty_like(grid.H))
+            for p in pmls:
+                if getattr(p, "_psiE_alt", None) is None:
+                    p._psiE_alt = torch.empty_like(p._psiE)
         if into is None:
             grid.E, grid.H = E.detach().clone(), H.detach().clone()
         lib = grid._ensure_plan(steps=n)   # binds the state tensors
@@ -135,7 +133,7 @@ class _Run(torch.autograd.Function):
             if into is not None:
                 kind = grid._native_run(lib, 1, into=True)
                 # the roles are exchanged: the new tensors hold the state
-                grid.E, grid.H = into
+                grid._bind_state(*into)
                 grid._step_buffers = None      # (the inputs: not ours to write to later)
                 if kind == 1:                  # psi_E went into the PMLs' second buffers
                     for n_p, p in enumerate(pmls):
@@ -179,7 +177,12 @@ class _Run(torch.autograd.Function):
         lam_psi = [start(g, (2,) + p.shape) for g, p in
                    zip(gpsi, [q for p in pmls for q in (p, p)])]
         grads = [torch.zeros_like(p.detach()) for p in params]
-        work = bd.zeros((grid.Nx * grid.Ny * grid.Nz, 6))
+        # (every entry of the work array that a reverse step reads it has written before: the
+        # array of the node before this one serves as it is)
+        work = getattr(grid, "_adjoint_work", None)
+        if work is None or work.dtype != bd.float or work.device != bd.device \
+                or work.shape[0] != grid.Nx * grid.Ny * grid.Nz:
+            work = grid._adjoint_work = bd.zeros((grid.Nx * grid.Ny * grid.Nz, 6))
         lib = grid._ensure_plan()
         plan = grid._plan
         for o, tr, gr in zip(objs, ctx.traces, grads):
@@ -242,7 +245,7 @@ def differentiable_advance(grid, n):
         if getattr(src, "_no_autograd", None):
             raise NotImplementedError(f"differentiable runs do not cover {src._no_autograd}")
     objs, pmls = _learnable(grid), _active_pmls(grid)
-    grid._fields()
+    grid._fields()       # (E and H validated here; the node works on aliases of them)
     if n >= 2:
         grid._provide_step_buffers()   # small grids: one launch per recorded step as well
     inputs = [o.inverse_permittivity for o in objs]
@@ -250,13 +253,18 @@ def differentiable_advance(grid, n):
         inputs += [o.nonlin_conv.weight, o.nonlin_conv.bias]
     if any(hasattr(s, "_torch_inputs") for s in grid.sources):
         grid._ensure_plan()  # decides which sources have cells on this rank
-    for src in _modulated_sources(grid):
+    srcs = _modulated_sources(grid)
+    for src in srcs:
         P, osc = src._torch_inputs(grid.time_steps_passed, max(n, 1))
         inputs += [P, osc, src.nonlin_conv.weight, src.nonlin_conv.bias]
     for p in pmls:
         inputs += [p._psiE, p._psiH]
+    grid._tape_lists = (objs, pmls, _modulated(objs), srcs)
     out = _Run.apply(grid, n, grid.E, grid.H, *inputs)
-    grid.E, grid.H = out[0], out[1]
+    if out[0].is_contiguous() and out[1].is_contiguous():
+        grid._bind_state(out[0], out[1])
+    else:
+        grid.E, grid.H = out[0], out[1]
     for n_p, p in enumerate(pmls):
         p._psiE, p._psiH = out[2 + 2 * n_p], out[3 + 2 * n_p]
     if n > 0:

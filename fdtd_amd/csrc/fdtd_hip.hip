@@ -116,6 +116,18 @@ int fdtdhip_plan_set_halo(fdtdhip_plan* p, const void* H_below, const void* E_ab
   return 0;
 }
 
+int fdtdhip_plan_bind(fdtdhip_plan* p, void* stream, void* E, void* H, const void* inv_eps,
+                      const void* inv_mu, void* E_alt, void* H_alt, const void* H_below,
+                      const void* E_above) {
+  if (int rc = fdtdhip_plan_set_fields(p, E, H, inv_eps, inv_mu)) return rc;
+  p->stream = (hipStream_t)stream;
+  p->E_alt = E_alt;
+  p->H_alt = H_alt;
+  p->H_below = H_below;
+  p->E_above = E_above;
+  return 0;
+}
+
 int fdtdhip_plan_add_pml(fdtdhip_plan* p, int axis, int side, int t, const double* bE,
                          const double* cE, const double* bH, const double* cH, void* psiE,
                          void* psiH) {
@@ -528,6 +540,8 @@ int fdtdhip_plan_whole_step_kind(fdtdhip_plan* p, int staged, int32_t core[6], i
   }
   return (int)kind;
 }
+
+int64_t fdtdhip_two_step_launches(void) { return fdtdhip::two_step_launches; }
 
 int fdtdhip_plan_two_step_box(fdtdhip_plan* p, int staged, int32_t inner[6]) {
   if (!p) return fail(-1, "null plan");

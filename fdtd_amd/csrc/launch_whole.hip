@@ -680,7 +680,8 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
   for (const DetH& d : p->dets) {
     if (d.kind != FDTDHIP_DET_CELLS || d.n == 0) continue;
     if (dets.count >= MARCH2_MAX_DETS) return fail(-1, "internal: more detectors than two steps per pass serve");
-    if (!d.outE || !d.outH || d.usedE + 2 > d.capacity || d.usedH + 2 > d.capacity)
+    // (two rows per pair; a call for a later piece of a pair in stages finds the first one taken)
+    if ((pieces & PST_INNER) && (!d.outE || !d.outH || d.usedE + 2 > d.capacity || d.usedH + 2 > d.capacity))
       return fail(-3, "detector output capacity exhausted");
     dets.cell[dets.count] = d.cell;
     dets.outE[dets.count] = (T*)d.outE + d.usedE * d.n * 3;
@@ -731,6 +732,7 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
     hipLaunchKernelGGL(kernel, grid, block, 0, p->stream, m);
     HIPCHK(hipGetLastError());
     if (int rc = span_end(p, slot, TIME_PAIR)) return rc;
+    ++two_step_launches;
     if (dets.count > 0) {
       hipLaunchKernelGGL((march2_detect_first_step<T>), dim3(blocks_for(dets.first[dets.count])), dim3(256), 0,
                          p->stream, m, dets);

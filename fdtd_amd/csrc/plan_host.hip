@@ -146,6 +146,8 @@ double waveform(const SourceH& s, int64_t q) {
 }
 
 // The E pass of a step filled one row of the objects' curl traces.
+int64_t two_step_launches = 0;
+
 void advance_trace_cursor(fdtdhip_plan* p) {
   if (p->trace_cursor < 0) return;
   ++p->trace_cursor;

@@ -280,6 +280,15 @@ class Grid:
         self._fields_seen = seen
         return out
 
+    def _bind_state(self, E, H):
+        """Bind E and H to tensors known to be device-resident, contiguous and of the backend
+        precision (results of a step, or detached aliases of validated tensors): ``_fields``
+        then recognises them without looking at their properties again."""
+        self.E, self.H = E, H
+        seen = self.__dict__.setdefault("_fields_seen", {})
+        seen["E"] = (weakref.ref(E), bd.float, bd.device)
+        seen["H"] = (weakref.ref(H), bd.float, bd.device)
+
     def _signature(self):
         sig = [bd.float, bd.device]
         for group in (self.boundaries, self.objects, self.sources, self.detectors):
@@ -324,31 +333,29 @@ class Grid:
                     link(lib, self._plan)
             self._plan_signature = sig
             self._materials_key = None
-        _lib.check(lib.fdtdhip_plan_set_stream(self._plan, _stream_ptr(bd.device)))
-        _lib.check(lib.fdtdhip_plan_set_fields(
-            self._plan, E.data_ptr(), H.data_ptr(), ie.data_ptr(), im.data_ptr()))
-        self._scan_materials(lib, ie, im, steps)
-        for group in (self.objects, self.boundaries):
-            for o in group:
-                refresh = getattr(o, "_native_refresh", None)
-                if refresh is not None:
-                    refresh(lib, self._plan)
+            # (the components that follow re-bound arrays between runs, in the order of old)
+            self._refreshed = [o for group in (self.objects, self.boundaries) for o in group
+                               if getattr(o, "_native_refresh", None) is not None]
         alt = getattr(self, "_step_buffers", None)
         if alt is not None and (alt[0].shape != E.shape or alt[0].dtype != E.dtype
                                 or alt[0].device != E.device):
             alt = self._step_buffers = None
-        _lib.check(lib.fdtdhip_plan_set_step_buffers(
-            self._plan, alt[0].data_ptr() if alt else None, alt[1].data_ptr() if alt else None))
         lo, hi = self._halo
-        if any(t is not None and (t.dtype != bd.float or t.device != bd.device) for t in (lo, hi)):
-            lo, hi = (None if t is None else t.to(device=bd.device, dtype=bd.float).contiguous()
-                      for t in (lo, hi))
-            self._halo = (lo, hi)
-            if hasattr(self, "_H_below"):
-                self._H_below, self._E_above = lo, hi
-        _lib.check(lib.fdtdhip_plan_set_halo(
-            self._plan, lo.data_ptr() if lo is not None else None,
-            hi.data_ptr() if hi is not None else None))
+        if lo is not None or hi is not None:
+            if any(t is not None and (t.dtype != bd.float or t.device != bd.device) for t in (lo, hi)):
+                lo, hi = (None if t is None else t.to(device=bd.device, dtype=bd.float).contiguous()
+                          for t in (lo, hi))
+                self._halo = (lo, hi)
+                if hasattr(self, "_H_below"):
+                    self._H_below, self._E_above = lo, hi
+        # stream, fields, step buffers and halo planes in one call
+        _lib.check(lib.fdtdhip_plan_bind(
+            self._plan, _stream_ptr(bd.device), E.data_ptr(), H.data_ptr(), ie.data_ptr(), im.data_ptr(),
+            alt[0].data_ptr() if alt else None, alt[1].data_ptr() if alt else None,
+            lo.data_ptr() if lo is not None else None, hi.data_ptr() if hi is not None else None))
+        self._scan_materials(lib, ie, im, steps)
+        for o in self._refreshed:
+            o._native_refresh(lib, self._plan)
         return lib
 
     _MAX_MATERIAL_SCANS = 4

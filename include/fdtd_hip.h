@@ -95,6 +95,14 @@ int fdtdhip_plan_set_fields(fdtdhip_plan* plan, void* E, void* H,
  * update_H for the last plane.  NULL = true domain edge. */
 int fdtdhip_plan_set_halo(fdtdhip_plan* plan, const void* H_below, const void* E_above);
 
+/* fdtdhip_plan_set_stream, fdtdhip_plan_set_fields, fdtdhip_plan_set_step_buffers and
+ * fdtdhip_plan_set_halo in one call, for hosts that bind everything before every step and pay
+ * for each crossing of the boundary (a loop that records one step per tape node, reference
+ * cortical/autoencoder.py:108-112).  NULL for the optional arrays as in the single calls. */
+int fdtdhip_plan_bind(fdtdhip_plan* plan, void* stream, void* E, void* H,
+                      const void* inv_permittivity, const void* inv_permeability, void* E_alt,
+                      void* H_alt, const void* H_below, const void* E_above);
+
 /* PML slab (reference fdtd/boundaries.py:356-476).  axis 0..2, side 0 = low /
  * 1 = high, `thickness` cells.  bE,cE,bH,cH: HOST arrays of `thickness`
  * doubles, the normal-axis component of the reference's bE/cE/bH/cH
@@ -273,6 +281,9 @@ int fdtdhip_plan_set_step_buffers(fdtdhip_plan* plan, void* E_alt, void* H_alt);
  * one after the other (no reference counterpart; benchmarks use it to
  * price the kernels). */
 int fdtdhip_plan_two_step_box(fdtdhip_plan* plan, int staged, int32_t inner[6]);
+/* How many launches of the two-step kernels this process has made so far, over all plans (no
+ * reference counterpart; random-scene tests use it to tell which scenes took that path). */
+int64_t fdtdhip_two_step_launches(void);
 /* A pair of steps (time indices q, q + 1) of an x-slab in eight pieces around its four plane
  * exchanges (`staged` != 0 above asks whether the plan can take them), the counterpart of
  * fdtdhip_step_stage for two steps per pass.  With the fields in the first buffers A and the

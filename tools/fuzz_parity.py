@@ -20,15 +20,19 @@ big = "big" in sys.argv[4:]
 extras = "extras" in sys.argv[4:]
 substrate = "substrate" in sys.argv[4:]
 crowded = "crowded" in sys.argv[4:]
-bad = skipped = 0
+bad = skipped = paired = 0
+from fdtd_amd import _lib  # noqa: E402
+
 for seed in range(first, first + count):
+    before = _lib.load().fdtdhip_two_step_launches()
     out = test_fuzz.check_scene(seed, dtype, big=big, extras=extras, substrate=substrate,
                                 crowded=crowded)
+    paired += _lib.load().fdtdhip_two_step_launches() > before
     if out is None:
         skipped += 1
     elif out[0]:
         bad += 1
         print(f"seed {seed}: {out[0]}\n   {out[1]}", flush=True)
 print(f"{dtype}{' big' if big else ''} seeds {first}..{first + count - 1}: {bad} above tolerance, "
-      f"{skipped} non-finite in the oracle (skipped)", flush=True)
+      f"{skipped} non-finite in the oracle (skipped); {paired} scenes took two steps per pass", flush=True)
 sys.exit(1 if bad else 0)

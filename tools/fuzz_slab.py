@@ -129,6 +129,7 @@ def worker(rank, world, port, seeds, on_gpu, out, crowded=None):
             if rank == 0:
                 results[f"E{seed}"], results[f"H{seed}"] = E, H
                 results[f"whole{seed}"] = np.array(getattr(grid, "whole_steps_taken", 0))
+                results[f"pairs{seed}"] = np.array(getattr(grid, "pair_steps_taken", 0))
                 for key in mine:   # the ranks hold consecutive cells of the detector
                     results[f"{key}_{seed}"] = np.concatenate([p[key] for p in parts], axis=1)
         if rank == 0:
@@ -158,6 +159,7 @@ def oracle_results(scene):
 
 
 WHOLE_STEP_SCENES = 0
+PAIR_SCENES = 0
 
 
 def run(world, first, count, on_gpu, out, crowded=None):
@@ -167,6 +169,8 @@ def run(world, first, count, on_gpu, out, crowded=None):
     bad = {}
     global WHOLE_STEP_SCENES   # scenes in which rank 0 advanced by whole steps in stages
     WHOLE_STEP_SCENES = sum(int(z[f"whole{seed}"]) > 0 for seed in seeds)
+    global PAIR_SCENES          # ... by two steps per pass in stages
+    PAIR_SCENES = sum(int(z[f"pairs{seed}"]) > 0 for seed in seeds)
     for seed in seeds:
         for name, want in oracle_results(make_scene(seed, crowded)).items():
             got = z[f"{name}{seed}"] if name in ("E", "H") else z[f"{name}_{seed}"]
@@ -180,6 +184,11 @@ def run(world, first, count, on_gpu, out, crowded=None):
             # nearly equal field values, as in tests/test_fuzz.py
             tol = 1e-12 if not flag("FLOAT32") else (1e-3 if name.endswith("_I") else 1e-5)
             if not err <= tol:
+                # (float32: a loop current is a sum of differences of H values; while it is
+                # far below their rounding -- the wave has not reached the loop -- it reads 0)
+                if flag("FLOAT32") and name.endswith("_I") and \
+                        np.abs(got - want).max() <= 1e-6 * np.abs(z[f"H{seed}"]).max():
+                    continue
                 bad.setdefault(seed, {})[name] = err
     return seeds, bad
 
@@ -192,6 +201,6 @@ if __name__ == "__main__":
         print(f"seed {seed}: {errs}\n   {make_scene(seed)}")
     print(f"x{world} {'gpu' if on_gpu else 'cpu'}: {len(seeds)} scenes "
           f"({sum(crosses(make_scene(s), world) for s in seeds)} with a current loop across slabs), "
-          f"{WHOLE_STEP_SCENES} advanced by whole steps in stages, "
+          f"{WHOLE_STEP_SCENES} advanced by whole steps in stages ({PAIR_SCENES} of them two steps per pass), "
           f"{len(bad)} above {'1e-5' if flag('FLOAT32') else '1e-12'}")
     sys.exit(1 if bad else 0)
