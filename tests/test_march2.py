@@ -360,3 +360,23 @@ def test_two_steps_per_pass_with_pml_faces():
                           capture_output=True, text=True, timeout=280, cwd=here)
     assert done.returncode == 0 and "two steps per pass with faces" in done.stdout, \
         done.stdout[-2000:] + done.stderr[-3000:]
+
+
+def test_random_plans_take_two_steps_per_pass_and_equal_half_steps_bitwise():
+    """Random plans (tools/fuzz_pairs.py: any subset of the faces with PMLs of 1-7 cells, up
+    to three objects of the plain kinds anywhere, up to eight source points, line and block
+    detectors, runs split in two calls) stepped two steps per pass, one step per pass and by
+    explicit half steps: fields, memory variables and detector readings bit for bit."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    tool = os.path.join(os.path.dirname(here), "tools", "fuzz_pairs.py")
+    for first, count, dtype in ((100, 30, "float32"), (200, 20, "float64")):
+        done = subprocess.run([sys.executable, tool, str(first), str(count), dtype],
+                              env=dict(os.environ, FDTDHIP_FUSED="2"), capture_output=True, text=True,
+                              timeout=280, cwd=here)
+        assert done.returncode == 0 and " 0 differ" in done.stdout, done.stdout[-2000:] + done.stderr[-3000:]
+        # (nearly every such plan allows pairs; the count keeps the comparison from being empty)
+        took = int(done.stdout.rsplit("differ,", 1)[1].split()[0])
+        assert took >= count * 3 // 4, done.stdout[-500:]
