@@ -320,3 +320,62 @@ def test_thousand_steps_against_the_oracle(dtype):
     scale = np.abs(o.H).max() * o.grid_spacing
     twin_I = np.array(tc.I, dtype=np.float64).reshape(steps)
     assert np.abs(currents - twin_I).max() <= 1e-5 * max(scale, np.abs(twin_I).max())
+
+
+def _benchmark_scene_with_objects_in_one_hull():
+    """configs[2] as the benchmark lays it out (both objects in one hull of 256 x 64 x 64 cells,
+    so that the plan marches), every cell of E and H set to noise, sources also inside the
+    faces and next to the objects, detectors through faces, objects and core."""
+    n = N_FULL
+    g = fdtd.Grid((n,) * 3)
+    for axis in range(3):
+        lo, hi = [slice(None)] * 3, [slice(None)] * 3
+        lo[axis], hi[axis] = slice(0, PML_T), slice(-PML_T, None)
+        g[tuple(lo)] = fdtd.PML()
+        g[tuple(hi)] = fdtd.PML()
+    for cell, period in (((n // 2, n // 2, n // 2), 20), ((3, 500, 11), 13), ((126, 130, 190), 9),
+                         ((200, 150, 160), 7), ((11, 12, 13), 17), ((n - 1, n - 1, n - 1), 5)):
+        g[cell] = fdtd.PointSource(period=period)
+    ani = fdtd.AnisotropicObject(permittivity=2.5)
+    g[128:192, 128:192, 128:192] = ani
+    with torch.no_grad():
+        ani.inverse_permittivity += fdtd.backend.array(_aniso_tensor()[1])
+    g[320:384, 128:192, 128:192] = fdtd.AbsorbingObject(permittivity=2.0, conductivity=1e-3)
+    dets = [fdtd.LineDetector(), fdtd.LineDetector(), fdtd.LineDetector()]
+    g[0:n - 1, 160, 150] = dets[0]       # through both objects and both x faces
+    g[256, 0:n - 1, 256] = dets[1]
+    g[130, 131, 0:n - 1] = dets[2]
+    gen = torch.Generator(device=g.E.device).manual_seed(5)
+    with torch.no_grad():
+        for f in (g.E, g.H):
+            f.uniform_(-1e-2, 1e-2, generator=gen)
+    return g, dets
+
+
+@pytest.mark.gpu
+def test_benchmark_scene_at_512_cubed_two_steps_per_pass_equal_one_step_per_pass_bitwise(monkeypatch):
+    """configs[2] at full size with noise in every cell: nine steps by the default policy (a
+    step of half steps, two groups of two passes of two steps each over 488^3 cells with the
+    faces, the layers next to them and the hull of the objects stepping beside them) against
+    the same run with FDTDHIP_MARCH2=0 (one step per pass) -- fields, memory variables of the
+    six faces and the three detectors' readings of every step, bit for bit."""
+    from fdtd_amd import _lib
+
+    fdtd.set_backend("hip.float32")
+    lib = _lib.load()
+    monkeypatch.delenv("FDTDHIP_FUSED", raising=False)
+    kept = {}
+    for way in ("pairs", "single"):
+        if way == "single":
+            monkeypatch.setenv("FDTDHIP_MARCH2", "0")
+        before = lib.fdtdhip_two_step_launches()
+        g, dets = _benchmark_scene_with_objects_in_one_hull()
+        g.run(9, progress_bar=False)
+        torch.cuda.synchronize()
+        assert lib.fdtdhip_two_step_launches() - before == (4 if way == "pairs" else 0)
+        kept[way] = ([g.E, g.H] + [t for b in g.boundaries for t in (b._psiE, b._psiH)]
+                     + [torch.stack(list(d.E)) for d in dets] + [torch.stack(list(d.H)) for d in dets])
+        del g
+    assert float(kept["pairs"][0].abs().max()) > 0
+    for n, (a, b) in enumerate(zip(kept["pairs"], kept["single"])):
+        assert torch.equal(a, b), n
