@@ -7,14 +7,16 @@ half step) of the whole grid; `value` is cell-updates per second summed over all
 GPUs with the fields resident in HBM.
 
 Workloads (all synthetic, fields start at small random values, a point source drives them):
-  m3v   512^3 float32, vacuum, PointSource            (default for one GPU: the "512^3
-        float32 Yee update" the headline metric is quoted on)
+  m3v   512^3 float32 per GPU, vacuum, PointSource    (default: the "512^3 float32 Yee
+        update" the headline metric is quoted on; with --gpus N a (512 N) x 512 x 512 grid in
+        N x-slabs, the same work per GPU)
   m3    512^3 float32, 6 PML(10), anisotropic + absorbing objects, 3 LineDetectors
   m2    256^3 float64, 6 PML(10), PointSource
   m3v64 512^3 float64, vacuum, PointSource
   c1    161x97x1 float64, the reference's README example
-  m4    256x1024x1024 float32 per GPU, 6 PML(10), PointSource (default for N > 1: with
-        --gpus 8 the 2048x1024x1024 x-slab configuration)
+  m4    256x1024x1024 float32 per GPU, 6 PML(10), PointSource (with --gpus 8 the
+        2048x1024x1024 x-slab configuration; measured after the default workload of a run on
+        several GPUs and reported as also.m4)
 With --gpus N > 1 the grid is N slabs of the single-GPU size along x (weak scaling), one
 process per GPU, the two tangential components of one halo plane exchanged per half step
 over RCCL.  Started as a plain `python bench.py --gpus N` the script launches its N ranks
@@ -239,8 +241,8 @@ def roofline(grid, cells, es, timing, mask, steps, workload):
         pass_ms = (ms[4] + ms[3]) / n[4]
         roof.update({
             "kernel": ("two-step marching kernel (E and H advanced twice in one pass)" if inner == cells else
-                       "two-step marching kernel over the cells three or more away from PML faces; "
-                       "two steps of half-step launches over the others"),
+                       "two-step marching kernel over the cells three or more away from PML faces, objects and "
+                       "open slab faces; two steps of half-step launches over the others"),
             "kernel_cells": inner, "grid_cells": cells,
             "shell_ms_per_step": round(ms[3] / steps, 4),
             "steps_per_launch": 2, "launches_per_step": round(n[4] / steps, 2),
@@ -458,7 +460,7 @@ def main():
     # (half a second or more of timed kernels by default: a sampling monitor beside the run sees it)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=None, help="default: m3v on one GPU, m4 slabs on several")
+    ap.add_argument("--workload", default=None, help="default: m3v (on several GPUs also m4, as also.m4)")
     ap.add_argument("--materials", choices=("auto", "arrays"), default="auto")
     ap.add_argument("--no-also", action="store_true",
                     help="leave out the `also` records (other configurations, sustained run)")
@@ -482,7 +484,7 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     default_run = args.workload is None
-    workload = args.workload or ("m3v" if world == 1 else "m4")
+    workload = args.workload or "m3v"
     # one rank per GPU; FDTD_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals
     backend = os.environ.get("FDTD_DIST_BACKEND", "nccl")
     device = local_rank % torch.cuda.device_count()
@@ -545,63 +547,77 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
         return float(t.item())
 
-    # on several GPUs rank 0 first times, on its own, a one-GPU grid of the per-GPU size of the
-    # same workload (the other ranks wait).  It is NOT one of the run's slabs: it carries the PMLs
-    # of all six faces and exchanges nothing, where a slab has at most one x face and one or two
-    # neighbours (tools/slab_step_cost.py times real slabs with their exchanges on one GPU)
-    one_slab = None
-    if world > 1:
-        if rank == 0 and workload != "c1":
-            one_slab = measure_single(workload, args.steps, args.warmup, args.materials)
+    def measure(workload, steps, warmup):
+        """One workload on all ranks of this job (a grid on one GPU, x-slabs on several);
+        rank 0 returns the record, the others None."""
+        # on several GPUs rank 0 first times, on its own, a one-GPU grid of the per-GPU size of the
+        # same workload (the other ranks wait).  It is NOT one of the run's slabs: it carries the
+        # boundaries of all six faces and exchanges nothing, where a slab has at most one closed x
+        # face and one or two neighbours (tools/slab_step_cost.py times real slabs with their
+        # exchanges on one GPU)
+        one_slab = None
+        if world > 1:
+            if rank == 0 and workload != "c1":
+                one_slab = measure_single(workload, steps, warmup, args.materials)
+            sync()
+        grid, cells, es, dt, desc = build_workload(fdtd, workload, world, rank, data_group)
+        if args.materials == "arrays":
+            use_material_arrays(grid, lib, _lib)
+        with torch_no_grad():
+            grid.run(warmup, progress_bar=False)
         sync()
+        mask = 0 if args.materials == "arrays" else _lib.check(lib.fdtdhip_plan_scan_materials(grid._plan, 1))
+        if workload == "c1":
+            # launch-bound: the step rate is timed without per-launch events, the kernel
+            # durations come from a second pass of the same steps with them
+            elapsed = timed_run(grid, lib, _lib, steps, sync, events=False)[0]
+            _, timing = timed_run(grid, lib, _lib, steps, sync)
+        else:
+            elapsed, timing = timed_run(grid, lib, _lib, steps, sync)
+        elapsed = max_over_ranks(elapsed)
+        out = None
+        if rank == 0:
+            value = cells * world * steps / elapsed / 1e9
+            # (this rank's own cells: the slabs of a run may differ in thickness)
+            roof = roofline(grid, grid.Nx * grid.Ny * grid.Nz, es, timing, mask, steps, workload)
+            roof["launches"] = sum(timing["n"])
+            out = {
+                "metric": "Yee cell-updates/s", "value": round(value, 3), "unit": "Gcells/s",
+                "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
+                "config": {"workload": desc, "name": workload,
+                           "parallelism": f"x-slab x{world}" if world > 1 else "single GPU",
+                           "cells_per_gpu": cells,
+                           **({"transport": transport,
+                               "halo": f"{grid.Ny}x{grid.Nz}x2 {dt} per half step and neighbour",
+                               "planes_per_rank": slab_planes(workload, cells // (grid.Ny * grid.Nz), world)
+                                                  or "even"} if transport else {})},
+                "roofline": roof,
+            }
+            if one_slab is not None:
+                one_slab["note"] = ("a one-GPU grid of the per-GPU size with the boundaries of all six faces "
+                                    "and no exchange; not one of this run's slabs")
+                out["one_gpu_grid_of_slab_size"] = one_slab
+        del grid
+        torch.cuda.empty_cache()
+        return out
 
-    grid, cells, es, dt, desc = build_workload(fdtd, workload, world, rank, data_group)
-    if args.materials == "arrays":
-        use_material_arrays(grid, lib, _lib)
-    with torch_no_grad():
-        grid.run(args.warmup, progress_bar=False)
-    sync()
-    mask = 0 if args.materials == "arrays" else _lib.check(lib.fdtdhip_plan_scan_materials(grid._plan, 1))
-    if workload == "c1":
-        # launch-bound: the step rate is timed without per-launch events, the kernel
-        # durations come from a second pass of the same steps with them
-        elapsed = timed_run(grid, lib, _lib, args.steps, sync, events=False)[0]
-        _, timing = timed_run(grid, lib, _lib, args.steps, sync)
-    else:
-        elapsed, timing = timed_run(grid, lib, _lib, args.steps, sync)
-    elapsed = max_over_ranks(elapsed)
-
-    out = None
-    if rank == 0:
-        value = cells * world * args.steps / elapsed / 1e9
-        # (this rank's own cells: the slabs of a run may differ in thickness)
-        roof = roofline(grid, grid.Nx * grid.Ny * grid.Nz, es, timing, mask, args.steps, workload)
-        roof["launches"] = sum(timing["n"])
-        out = {
-            "metric": "Yee cell-updates/s", "value": round(value, 3), "unit": "Gcells/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
-            "config": {"workload": desc, "name": workload,
-                       "parallelism": f"x-slab x{world}" if world > 1 else "single GPU",
-                       "cells_per_gpu": cells,
-                       **({"transport": transport,
-                           "halo": f"{grid.Ny}x{grid.Nz}x2 {dt} per half step and neighbour",
-                           "planes_per_rank": slab_planes(workload, cells // (grid.Ny * grid.Nz), world)
-                                              or "even"} if transport else {})},
-            "roofline": roof,
-        }
-        if one_slab is not None:
-            one_slab["note"] = ("a one-GPU grid of the per-GPU size with the PMLs of all six faces and no "
-                                "exchange; not one of this run's slabs")
-            out["one_gpu_grid_of_slab_size"] = one_slab
-            # the weak-scaling series of this workload starts at that grid, not at the one-GPU
-            # headline (512^3 vacuum, another workload and, with two steps per launch, another kernel)
-            out["scaling_note"] = ("weak-scaling series of '" + workload + "': its one-GPU point is "
-                                   "one_gpu_grid_of_slab_size.value here (= also." + workload + " of the "
-                                   "default one-GPU line); the one-GPU headline value belongs to another workload")
-    del grid
-    torch.cuda.empty_cache()
+    # On several GPUs the series stays the one-GPU headline's: every GPU holds a 512^3 float32
+    # vacuum slab of a (512 N) x 512 x 512 grid, the same work per GPU as `--gpus 1` times --
+    # weak scaling of one workload.  The 8-GPU configuration proper (256 x 1024 x 1024 per GPU
+    # with the PMLs of the whole simulation, `m4`) is measured by the same ranks right after it
+    # and reported as also.m4 (with its own one-GPU point).
+    out = measure(workload, args.steps, args.warmup)
+    if world > 1 and default_run and not args.no_also:
+        m4 = measure("m4", min(args.steps, 200), min(args.warmup, 10))
+        if rank == 0:
+            for k in ("metric", "unit", "higher_is_better", "vs_baseline", "data"):
+                m4.pop(k, None)
+            m4["note"] = ("the 8-GPU configuration's slabs (256 x 1024 x 1024 cells per GPU, PMLs of the whole "
+                          "simulation): its weak-scaling series starts at one_gpu_grid_of_slab_size.value in "
+                          "this record (= also.m4 of the one-GPU line)")
+            out["also"] = {"m4": m4}
     if rank == 0 and world == 1 and default_run and not args.no_also:
         # the other benchmark configurations, measured by this same run
         also = {}

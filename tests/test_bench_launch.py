@@ -25,13 +25,18 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1, done.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
-    assert out["config"]["name"] == "m4"                       # 256 x 1024 x 1024 per rank
-    assert out["config"]["workload"].startswith("512x1024x1024 f32")
+    # the headline's series: a 512^3 vacuum slab per rank ...
+    assert out["config"]["name"] == "m3v" and out["config"]["cells_per_gpu"] == 512 ** 3
+    assert out["config"]["workload"].startswith("1024x512x512 f32")
     assert "gloo" in out["config"]["transport"]
-    assert out["config"]["halo"].startswith("1024x1024x2")
+    assert out["config"]["halo"].startswith("512x512x2")
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
-    assert out["one_gpu_grid_of_slab_size"]["name"] == "m4"
-
+    assert out["one_gpu_grid_of_slab_size"]["name"] == "m3v"
+    # ... and the slabs of the 8-GPU configuration, 256 x 1024 x 1024 per rank, beside it
+    m4 = out["also"]["m4"]
+    assert m4["config"]["name"] == "m4" and m4["config"]["workload"].startswith("512x1024x1024 f32")
+    assert m4["config"]["halo"].startswith("1024x1024x2") and m4["n_gpus"] == 2
+    assert m4["value"] > 0 and m4["one_gpu_grid_of_slab_size"]["name"] == "m4"
 
 def test_bench_help_needs_no_gpu():
     done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"],
