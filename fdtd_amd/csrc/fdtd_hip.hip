@@ -476,13 +476,16 @@ int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
     // plans with nothing between their steps but source points: two steps per pass, in
     // pairs of passes (first -> second buffers and back)
     if (pairs)
-      for (; s + 3 < nsteps; s += 4)
+      for (; s + 3 < nsteps; s += 4) {
+        if (int rc = capacity_check(p, 4)) return rc;      // (before anything is enqueued)
         for (int k = 0; k < 2; ++k)
           if (const int rc = whole_pair_step(p, q0 + s + 2 * k)) {
-            // (memory variables are advanced in place: a pass that stops half way cannot be repeated)
-            if (p->step_flipped || !p->pmls.empty()) p->poisoned = true;
+            // (the cells of PML faces and of the objects' box take the first step of a pair in
+            // place, memory variables included: a pass that stops half way cannot be repeated)
+            if (p->step_flipped || !p->pmls.empty() || !p->objs.empty()) p->poisoned = true;
             return rc;
           }
+      }
     for (; kind && s + 1 < nsteps; s += 2) {
       if (int rc = capacity_check(p, 2)) return rc;
       for (int k = 0; k < 2; ++k) {
@@ -561,6 +564,7 @@ int fdtdhip_pair_stage(fdtdhip_plan* p, int64_t q, int stage) {
     if (!p->E || !p->H || !p->inv_eps || !p->inv_mu) return fail(-1, "fields not set");
     if (!whole_pair_possible(p, nullptr, true))
       return fail(-1, "this plan cannot take two steps per pass in stages (fdtdhip_plan_two_step_box)");
+    if (int rc = capacity_check(p, 2)) return rc;      // (nothing enqueued yet: the plan stays usable)
   }
   const int rc = whole_pair_stage(p, q, stage);
   // (fields and memory variables are advanced in place: a pair that stops half way cannot be repeated)
