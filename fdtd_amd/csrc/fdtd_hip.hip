@@ -476,7 +476,7 @@ int fdtdhip_run(fdtdhip_plan* p, int64_t q0, int64_t nsteps) {
     // plans with nothing between their steps but source points: two steps per pass, in
     // pairs of passes (first -> second buffers and back)
     if (pairs)
-      for (; s + 3 < nsteps; s += 4) {
+      for (; s + 3 < nsteps && trace_rows_left(p) >= 4; s += 4) {
         if (int rc = capacity_check(p, 4)) return rc;      // (before anything is enqueued)
         for (int k = 0; k < 2; ++k)
           if (const int rc = whole_pair_step(p, q0 + s + 2 * k)) {

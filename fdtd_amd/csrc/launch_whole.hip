@@ -739,10 +739,9 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
       HIPCHK(hipGetLastError());
     }
   }
-  if (shell) {
-    T* EA = (T*)p->E; T* HA = (T*)p->H; T* EB = (T*)p->E_alt; T* HB = (T*)p->H_alt;
+  T* EA = (T*)p->E; T* HA = (T*)p->H; T* EB = (T*)p->E_alt; T* HB = (T*)p->H_alt;
+  const bool pml = !p->pmls.empty();
     // ghost = false: the cells outside `in` that wait for no ghost plane; true: the plane that does
-    const bool pml = !p->pmls.empty();
     auto half_step = [&](bool phaseE, bool ghost, const int (&in)[6], const int (&island)[6],
                          const T* F, const T* G, T* out) -> int {
       Shell sh;
@@ -758,6 +757,9 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
       BulkArgs<T> b = phaseE ? a.e : a.h;
       b.F = const_cast<T*>(F);
       b.G = G;
+      // (recorded runs: the E half steps of the objects' box write the curl of H into the
+      // current row of the objects' curl traces, which moves on after each step of the pair)
+      b.trace_step = phaseE ? p->trace_cursor : -1;
       if (int rc = span_begin(p, slot)) return rc;
       const dim3 sgrid((unsigned)sh.first[sh.count]), sblock(256);
       if (phaseE && pml && obj) hipLaunchKernelGGL((shell_E<T, true, true>), sgrid, sblock, 0, p->stream, b, out, sh);
@@ -772,6 +774,7 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
     auto add = [&](T* E, const ShellSources<T>& ss) {
       if (ss.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, E, ss);
     };
+  if (shell) {
     // first step, in place in A
     if (pieces & PST_E1_FREE) { if (int rc = half_step(true, false, e1, pb.hole4, EA, HA, EA)) return rc; add(EA, s1); }
     if ((pieces & PST_E1_GHOST) && lo_skip) { if (int rc = half_step(true, true, e1, pb.hole4, EA, HA, EA)) return rc; add(EA, g1); }
@@ -798,6 +801,13 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
       }
       HIPCHK(hipGetLastError());
     }
+  }
+  if (pieces & PST_H1_GHOST) {
+    for (DetH& d : p->dets)
+      if (d.kind == FDTDHIP_DET_CELLS) { ++d.usedE; ++d.usedH; }      // the first step's record row
+    advance_trace_cursor(p);                                          // ... and its row of the curl traces
+  }
+  if (shell) {
     // second step, from A into B
     if (pieces & PST_E2_FREE) { if (int rc = half_step(true, false, m.box, pb.hole2, EA, HA, EB)) return rc; add(EB, s2); }
     if ((pieces & PST_E2_GHOST) && lo_skip) { if (int rc = half_step(true, true, m.box, pb.hole2, EA, HA, EB)) return rc; add(EB, g2); }
@@ -805,17 +815,14 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
     if ((pieces & PST_H2_GHOST) && hi_skip) if (int rc = half_step(false, true, m.box, pb.hole2, HA, EB, HB)) return rc;
     HIPCHK(hipGetLastError());
   }
-  if ((pieces & PST_H1_GHOST) && !p->dets.empty())
-    for (DetH& d : p->dets)
-      if (d.kind == FDTDHIP_DET_CELLS) { ++d.usedE; ++d.usedH; }      // the first step's record row
   if (pieces & PST_H2_GHOST) {
     std::swap(p->E, p->E_alt);
     std::swap(p->H, p->H_alt);
     p->step_flipped = !p->step_flipped;
-    if (!p->dets.empty()) {      // the second step's readings: every cell's state is in memory
-      if (int rc = half_post(p, true, q + 1, POST_FINISH)) return rc;
-      if (int rc = half_post(p, false, q + 1, POST_FINISH)) return rc;
-    }
+    // the second step's readings: every cell's state is in memory (the E half's finish moves
+    // the row of the curl traces on)
+    if (int rc = half_post(p, true, q + 1, POST_FINISH)) return rc;
+    if (int rc = half_post(p, false, q + 1, POST_FINISH)) return rc;
   }
   return 0;
 }
@@ -839,8 +846,10 @@ bool whole_pair_possible(const fdtdhip_plan* p, int32_t inner_out[6], bool stage
     if (d.kind != FDTDHIP_DET_CELLS) return false;
     if (d.n > 0 && ++served > MARCH2_MAX_DETS) return false;
   }
+  // (a recorded run: room for the two rows of a pair in every object's curl trace)
+  if (trace_rows_left(p) < 2) return false;
   if (!(halo == staged &&
-        p->trace_cursor < 0 && p->nz >= MARCH2_ZOWN && p->mat_const[0] && p->mat_const[1] &&
+        p->nz >= MARCH2_ZOWN && p->mat_const[0] && p->mat_const[1] &&
         (int64_t)p->ny * p->nz * 3 * (p->dtype == FDTDHIP_F32 ? 4 : 8) < (1ll << 32) &&   // in-plane byte offsets
         pair_boxes(p, pb)))
     return false;

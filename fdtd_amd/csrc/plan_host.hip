@@ -148,6 +148,14 @@ double waveform(const SourceH& s, int64_t q) {
 // The E pass of a step filled one row of the objects' curl traces.
 int64_t two_step_launches = 0;
 
+int64_t trace_rows_left(const fdtdhip_plan* p) {
+  int64_t left = INT64_MAX;
+  if (p->trace_cursor < 0) return left;
+  for (const ObjH& o : p->objs)
+    if (o.trace) left = std::min<int64_t>(left, o.trace_capacity - p->trace_cursor);
+  return left;
+}
+
 void advance_trace_cursor(fdtdhip_plan* p) {
   if (p->trace_cursor < 0) return;
   ++p->trace_cursor;

@@ -223,6 +223,7 @@ int span_begin(fdtdhip_plan* p, size_t& slot);
 int span_end(fdtdhip_plan* p, size_t slot, int what);
 double waveform(const SourceH& s, int64_t q);
 void advance_trace_cursor(fdtdhip_plan* p);
+int64_t trace_rows_left(const fdtdhip_plan* p);   // rows the curl traces can still take; huge when none is recorded
 extern int64_t two_step_launches;   // launches of the two-step kernels in this process (diagnostics)
 int capacity_check(const fdtdhip_plan* p, int64_t n);
 size_t external_periodic(const fdtdhip_plan* p);

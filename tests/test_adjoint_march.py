@@ -149,3 +149,37 @@ def _finite_difference_case():
     h = 1e-4
     numeric = float(run(h, False)[0] - run(-h, False)[0]) / (2 * h)
     assert abs(adjoint - numeric) <= 1e-6 * abs(numeric), (adjoint, numeric)
+
+
+def _recorded_pairs_case():
+    from fdtd_amd import _lib
+
+    lib = _lib.load()
+    for dtype, shape in _CASES:
+        for faces, objects, steps in (("six-faces", True, 10), ("four-faces", "inside", 6), ("no-pml", True, 9)):
+            before = lib.fdtdhip_two_step_launches()
+            got = _gradients(dtype, shape, faces, objects, steps, second_buffers=True)
+            assert lib.fdtdhip_two_step_launches() - before == 2 * ((steps - 1) // 4), (dtype, faces, steps)
+            os.environ["FDTDHIP_MARCH2"] = "0"      # (read at every call)
+            try:
+                want = _gradients(dtype, shape, faces, objects, steps, second_buffers=True)
+            finally:
+                del os.environ["FDTDHIP_MARCH2"]
+            for name in want:
+                assert float(want[name].abs().max()) > 0, name
+                assert torch.equal(got[name], want[name]), f"{name}: {dtype} {shape} {faces} objects={objects}"
+
+
+def test_recorded_runs_take_two_steps_per_pass_and_give_the_same_gradients():
+    """A recorded run advances two steps per pass like any other where the plan allows it (the
+    E half steps of the objects' box, which the shell launches take, write the rows of the curl
+    traces one after the other).  Gradients with respect to the initial fields and to the
+    learnable tensor against the same run with FDTDHIP_MARCH2=0, bit for bit; FDTDHIP_FUSED=2
+    lets grids of these sizes march whatever their share of PML cells (read once per process,
+    hence the child)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (f"import sys\nsys.path[:0] = [{os.path.dirname(here)!r}, {here!r}]\n"
+            "import test_adjoint_march as t\nt._recorded_pairs_case()\nprint('same gradients')\n")
+    done = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FDTDHIP_FUSED="2"),
+                          capture_output=True, text=True, timeout=280, cwd=here)
+    assert done.returncode == 0 and "same gradients" in done.stdout, done.stdout[-2000:] + done.stderr[-2000:]
