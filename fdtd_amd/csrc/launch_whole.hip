@@ -830,10 +830,10 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
 }  // namespace
 
 // Whether runs of this plan may advance two steps per pass: a marching plan, both materials
-// constant, whose steps have nothing between them but additive source points -- no detector
-// to read, no curl trace to record, no object, no slab face -- and, with PML faces, room for
-// the boxes of pair_step (with material arrays to read twice the kernel is slower than two
-// one-step launches: 512^3 float32 2.26 against 1.81 ms per step).  FDTDHIP_MARCH2=0 in the
+// constant, detectors of the cell kind only and few of them, room for two more rows in the
+// curl traces of a recorded run, and room for the boxes of pair_step between the PML faces,
+// the objects' box and the open slab faces (with material arrays to read twice the kernel is
+// slower than two one-step launches: 512^3 float32 2.26 against 1.81 ms per step).  FDTDHIP_MARCH2=0 in the
 // environment: never (read at every call: tests compare the two ways of stepping in one process).
 bool whole_pair_possible(const fdtdhip_plan* p, int32_t inner_out[6], bool staged) {
   const char* e = getenv("FDTDHIP_MARCH2");

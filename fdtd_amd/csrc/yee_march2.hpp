@@ -3,8 +3,9 @@
 // step_march (yee_march.hpp) moves every field value through HBM once per step and spends its
 // time waiting for them.  A box of cells with nothing between its steps but additive point
 // sources (constant materials; PML faces, objects and slab faces at least three cells away and
-// stepped by other launches, detector cells read by the patch kernel at the end of this file; no
-// curl trace, no periodic boundary) can take two steps per pass: E and H are read once and written once per TWO steps, the state after the
+// stepped by other launches -- which also record the curl traces of a differentiable run --,
+// detector cells read by the patch kernel at the end of this file; no periodic boundary) can
+// take two steps per pass: E and H are read once and written once per TWO steps, the state after the
 // first one lives only in registers (reference fdtd/grid.py:267-295 run twice; the same sums on
 // the same operands, so the result equals two single steps bit for bit).
 //

@@ -83,8 +83,8 @@ class _NativeEngine:
 
     def pairs_possible(self):
         """Whether this slab's plan can advance two steps per pass in stages
-        (``fdtdhip_pair_stage``): whole steps possible, constant materials, no recorded curl,
-        detectors of the cell kind only, objects away from the open faces."""
+        (``fdtdhip_pair_stage``): whole steps possible, constant materials, detectors of the cell
+        kind only, objects away from the open faces (recorded runs included)."""
         return self.lib.fdtdhip_plan_two_step_box(self.plan, 1, None) == 1
 
     def pair_stage(self, q, stage):
