@@ -233,10 +233,14 @@ int fdtdhip_plan_add_source(fdtdhip_plan* p, int kind, int compE, int compH, int
     if (n < 0) return fail(-1, "negative point count");
     std::vector<int64_t> elem((size_t)n);
     std::set<int64_t> seen;
+    for (int i = 0; i < 6; ++i) s.box[i] = 0;      // the box that holds the points
     for (int64_t i = 0; i < n; ++i) {
-      for (int d = 0; d < 3; ++d)
+      for (int d = 0; d < 3; ++d) {
         if (cells[3 * i + d] < 0 || cells[3 * i + d] >= lim[d])
           return fail(-1, "source point outside the grid");
+        s.box[2 * d] = i == 0 ? cells[3 * i + d] : std::min(s.box[2 * d], cells[3 * i + d]);
+        s.box[2 * d + 1] = i == 0 ? cells[3 * i + d] + 1 : std::max(s.box[2 * d + 1], cells[3 * i + d] + 1);
+      }
       elem[i] = ((((int64_t)cells[3 * i] * p->ny) + cells[3 * i + 1]) * p->nz + cells[3 * i + 2]) * 3 + compE;
       if (!seen.insert(elem[i]).second) s.serial = 1;
       if (i == 0 || elem[i] < s.elem_min) s.elem_min = elem[i];
@@ -535,7 +539,7 @@ int fdtdhip_plan_whole_step_kind(fdtdhip_plan* p, int staged, int32_t core[6], i
   if (!p) return fail(-1, "null plan");
   const FusedKind kind = fused_kind(p, staged != 0);
   int c[6] = {0, p->nx, 0, p->ny, 0, p->nz}, h[6] = {0, 0, 0, 0, 0, 0};
-  const bool shell = !(p->pmls.empty() && p->objs.empty()) || p->H_below || p->E_above;
+  const bool shell = !(p->pmls.empty() && p->objs.empty()) || p->H_below || p->E_above || sources_by_launch(p);
   if (kind == FUSED_MARCH && shell && !march_core(p, c, h)) return fail(-1, "internal: no core box");
   for (int n = 0; n < 6; ++n) {
     if (core) core[n] = c[n];

@@ -367,6 +367,36 @@ int half_post(fdtdhip_plan* p, bool phaseE, int64_t q, int parts, int x0, int x1
                   post<double>(p, phaseE, q, parts, x0, x1, stage));
 }
 
+namespace {
+// Additive point lists and boxes that are set, at time index q, applied to F (post() applies
+// the same launches to the plan's current arrays, among the other kinds of source).
+template <typename T>
+int sources_to(fdtdhip_plan* p, bool phaseE, int64_t q, T* F) {
+  for (const SourceH& s : p->sources) {
+    const double w = waveform(s, q);
+    if (s.kind == FDTDHIP_SRC_ADD_POINTS) {
+      if (!phaseE || s.n == 0) continue;
+      hipLaunchKernelGGL((source_add_points<T>), dim3(s.serial ? 1 : blocks_for(s.n, 64)), dim3(64), 0,
+                         p->stream, F, s.elem, s.profile, w, s.n, s.serial, (int64_t)0, p->cells() * 3);
+    } else if (s.kind == FDTDHIP_SRC_SET_BOX) {
+      const int64_t total = (int64_t)(s.box[1] - s.box[0]) * (s.box[3] - s.box[2]) * (s.box[5] - s.box[4]);
+      if (total <= 0) continue;
+      hipLaunchKernelGGL((source_set_box<T>), dim3(blocks_for(total)), dim3(256), 0, p->stream, F, p->ny,
+                         p->nz, s.box[0], s.box[1], s.box[2], s.box[3], s.box[4], s.box[5],
+                         phaseE ? s.compE : s.compH, (T)(s.amplitude * w));
+    } else {
+      return fail(-1, "internal: a source of this kind is not applied apart from its half step");
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+int apply_sources_to(fdtdhip_plan* p, bool phaseE, int64_t q, void* F) {
+  return DISPATCH(p, sources_to<float>(p, phaseE, q, (float*)F), sources_to<double>(p, phaseE, q, (double*)F));
+}
+
 int half_read_deferred_currents(fdtdhip_plan* p) {
   return DISPATCH(p, read_deferred_currents<float>(p), read_deferred_currents<double>(p));
 }

@@ -57,6 +57,17 @@ bool march_owns(const fdtdhip_plan* p, const int (&core)[6], const int (&hole)[6
 
 }  // namespace
 
+bool sources_by_launch(const fdtdhip_plan* p) {
+  int64_t points = 0;
+  bool set_box = false;
+  for (const SourceH& s : p->sources) {
+    if (s.kind == FDTDHIP_SRC_SET_BOX) set_box = true;
+    else if (s.kind == FDTDHIP_SRC_ADD_POINTS && !s.serial) points += s.n;
+    else return false;
+  }
+  return set_box || points > MAX_STEP_SOURCES;
+}
+
 bool march_core(const fdtdhip_plan* p, int (&core)[6], int (&hole)[6]) {
   BulkArgs<float> b;
   fill_core<float>(p, b);
@@ -65,12 +76,25 @@ bool march_core(const fdtdhip_plan* p, int (&core)[6], int (&hole)[6]) {
   // step of the last plane) waits for the halo exchange: it belongs to the shell
   if (p->H_below) core[0] = std::max(core[0], 1);
   if (p->E_above) core[1] = std::min(core[1], p->nx - 1);
+  // the box the shell launches step inside the core: the objects, and the cells of sources that
+  // are applied by launches of their own between the half steps
+  int hull[6];
+  for (int n = 0; n < 6; ++n) hull[n] = b.hull[n];
+  const bool apart = sources_by_launch(p);
+  if (apart)
+    for (const SourceH& s : p->sources) {
+      if (s.box[1] <= s.box[0] || s.box[3] <= s.box[2] || s.box[5] <= s.box[4]) continue;
+      for (int ax = 0; ax < 3; ++ax) {
+        hull[2 * ax] = std::min(hull[2 * ax], s.box[2 * ax]);
+        hull[2 * ax + 1] = std::max(hull[2 * ax + 1], s.box[2 * ax + 1]);
+      }
+    }
   for (int ax = 0; ax < 3; ++ax) {
     if (core[2 * ax + 1] - core[2 * ax] < 1) return false;
-    hole[2 * ax] = std::min(std::max(b.hull[2 * ax], core[2 * ax]), core[2 * ax + 1]);
-    hole[2 * ax + 1] = std::min(std::max(b.hull[2 * ax + 1], hole[2 * ax]), core[2 * ax + 1]);
+    hole[2 * ax] = std::min(std::max(hull[2 * ax], core[2 * ax]), core[2 * ax + 1]);
+    hole[2 * ax + 1] = std::min(std::max(hull[2 * ax + 1], hole[2 * ax]), core[2 * ax + 1]);
   }
-  if (p->objs.empty() || hole[1] == hole[0] || hole[3] == hole[2] || hole[5] == hole[4])
+  if ((p->objs.empty() && !apart) || hole[1] == hole[0] || hole[3] == hole[2] || hole[5] == hole[4])
     for (int n = 0; n < 6; ++n) hole[n] = 0;
   return true;
 }
@@ -102,16 +126,18 @@ FusedKind fused_kind(const fdtdhip_plan* p, bool staged, double shell_share) {
     if (b.kind == 1) return FUSED_NONE;
   for (const PmlH& h : p->pmls)
     if (!h.psiE_alt) return FUSED_NONE;
-  int64_t points = 0;
-  for (const SourceH& s : p->sources) {
-    if (s.kind != FDTDHIP_SRC_ADD_POINTS || s.serial) return FUSED_NONE;
-    points += s.n;
-  }
-  if (points > MAX_STEP_SOURCES) return FUSED_NONE;
-  const bool cell_ok = p->nx <= 65535 && (int64_t)p->ny * p->nz < (1ll << 30) &&
+  // sources: point lists that add, up to MAX_STEP_SOURCES points in the kernels' registers;
+  // more of them, and boxes that are set, by launches of their own around the marching kernel
+  // (not on slabs, whose ghost planes take launches of their own already)
+  const bool apart = sources_by_launch(p);
+  for (const SourceH& s : p->sources)
+    if (!(s.kind == FDTDHIP_SRC_ADD_POINTS && !s.serial) && !(apart && s.kind == FDTDHIP_SRC_SET_BOX))
+      return FUSED_NONE;
+  if (apart && staged) return FUSED_NONE;
+  const bool cell_ok = !apart && p->nx <= 65535 && (int64_t)p->ny * p->nz < (1ll << 30) &&
                        p->cells() * 3 < (1ll << 31);   // the kernel's element offsets are 32-bit
   int core[6], hole[6] = {0, 0, 0, 0, 0, 0};
-  const bool whole_grid = p->pmls.empty() && p->objs.empty() && !halo;   // step_march, no shell
+  const bool whole_grid = p->pmls.empty() && p->objs.empty() && !halo && !apart;   // step_march, no shell
   const bool march_ok = (whole_grid || march_core(p, core, hole)) &&
                         p->nz <= 64 * MARCH_MAX_WAVES && p->nx / 16 <= 65535;
   // the cells that take half steps of their own next to the marching kernel
@@ -278,7 +304,7 @@ int launch_march(fdtdhip_plan* p, const StepArgs<T>& a, bool obj) {
 // operand.  Without open faces all pieces are enqueued at once, the core in one launch.
 
 template <typename T, int TY, int MW>
-int launch_march_shell_tiles(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, int stages) {
+int launch_march_shell_tiles(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, int stages, int64_t q) {
   int c[6], hole[6];
   if (!march_core(p, c, hole)) return fail(-1, "internal: no core box for the marching step");
   const int nx = p->nx, ny = p->ny, nz = p->nz;
@@ -352,6 +378,10 @@ int launch_march_shell_tiles(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, in
                                 {hole[0], hole[1], hole[2], hole[3], hole[4], hole[5]}})))
       return rc;
     if (ss_free.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, a.E1, ss_free);
+    // (sources applied apart: all their cells lie in the shell or in the box inside the core that
+    // the launch above stepped; the marching kernel reads their new E from the second buffer)
+    if (sources_by_launch(p))
+      if (int rc = apply_sources_to(p, true, q, a.E1)) return rc;
   }
   if (stages & ST_E_GHOST) {
     if (int rc = shell_e(table({{0, e_lo, 0, ny, 0, nz}}))) return rc;
@@ -388,15 +418,17 @@ int launch_march_shell_tiles(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, in
       return rc;
   if (stages & ST_H_GHOST)
     if (int rc = shell_h(table({{h_hi, nx, 0, ny, 0, nz}}))) return rc;
+  if ((stages & ST_H_FREE) && sources_by_launch(p))      // (boxes that are set: H after its half step)
+    if (int rc = apply_sources_to(p, false, q, a.H1)) return rc;
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 template <typename T>
-int launch_march_shell(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, int stages) {
+int launch_march_shell(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, int stages, int64_t q) {
   if ((p->nz + 63) / 64 <= 8)
-    return launch_march_shell_tiles<T, sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : FDTDHIP_MARCH_TY64, 8>(p, a, obj, stages);
-  return launch_march_shell_tiles<T, sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : 2, MARCH_MAX_WAVES>(p, a, obj, stages);
+    return launch_march_shell_tiles<T, sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : FDTDHIP_MARCH_TY64, 8>(p, a, obj, stages, q);
+  return launch_march_shell_tiles<T, sizeof(T) == 4 ? FDTDHIP_MARCH_TY32 : 2, MARCH_MAX_WAVES>(p, a, obj, stages, q);
 }
 
 // Kernel arguments of a whole step at time index q (both half steps, the second buffers,
@@ -431,7 +463,9 @@ int step_args(fdtdhip_plan* p, int64_t q, bool march, StepArgs<T>& a) {
   a.nsrc = 0;
   a.detmap = nullptr;
   for (int slot = 0; slot < MAX_STEP_DETECTORS; ++slot) a.detE[slot] = a.detH[slot] = nullptr;
+  const bool apart = sources_by_launch(p);
   for (const SourceH& s : p->sources) {
+    if (apart) break;      // (applied by launches of their own)
     const double w = waveform(s, q);
     for (int64_t i = 0; i < s.n; ++i) {
       if (a.nsrc >= MAX_STEP_SOURCES) return fail(-1, "internal: too many source points for a whole step");
@@ -484,8 +518,8 @@ int fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {
   const int64_t plane = (int64_t)p->ny * p->nz;
   const dim3 grid((unsigned)((plane + 255) / 256), p->nx, 1), block(256);
   const bool pml = a.e.npml > 0, obj = a.e.nobj > 0;
-  if (march && (pml || obj)) {
-    if (int rc = launch_march_shell<T>(p, a, obj, ST_ALL)) return rc;
+  if (march && (pml || obj || sources_by_launch(p))) {
+    if (int rc = launch_march_shell<T>(p, a, obj, ST_ALL, q)) return rc;
   } else {
     size_t slot;
     if (int rc = span_begin(p, slot)) return rc;
@@ -507,7 +541,7 @@ int staged_step(fdtdhip_plan* p, int64_t q, int stage) {
   StepArgs<T> a;
   if (int rc = step_args<T>(p, q, true, a)) return rc;
   static const int pieces[4] = {ST_E_FREE | ST_MARCH_A, ST_E_GHOST, ST_MARCH_B | ST_H_FREE, ST_H_GHOST};
-  if (int rc = launch_march_shell<T>(p, a, a.e.nobj > 0, pieces[stage])) return rc;
+  if (int rc = launch_march_shell<T>(p, a, a.e.nobj > 0, pieces[stage], q)) return rc;
   return stage == 3 ? step_finish<T>(p, q, false) : 0;
 }
 
@@ -600,7 +634,9 @@ void grown_hole(const int (&hole)[6], int m, const int (&box)[6], int (&out)[6])
 struct PairBoxes { int inner[6], e1[6], h1[6], hole2[6], hole4[6], hole3[6]; };
 bool pair_boxes(const fdtdhip_plan* p, PairBoxes& b) {
   int core[6] = {0, p->nx, 0, p->ny, 0, p->nz}, hole[6] = {0, 0, 0, 0, 0, 0};
-  if ((!p->pmls.empty() || !p->objs.empty() || p->H_below || p->E_above) && !march_core(p, core, hole)) return false;
+  if ((!p->pmls.empty() || !p->objs.empty() || p->H_below || p->E_above || sources_by_launch(p)) &&
+      !march_core(p, core, hole))
+    return false;
   if (!(shrunk_core(p, core, 2, b.inner) && shrunk_core(p, core, 3, b.h1) && shrunk_core(p, core, 4, b.e1)))
     return false;
   grown_hole(hole, 2, b.inner, b.hole2);
@@ -629,7 +665,7 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
   const int (&e1)[6] = pb.e1;
   const int (&h1)[6] = pb.h1;
   const bool obj = !p->objs.empty();
-  const bool shell = !p->pmls.empty() || obj || p->H_below || p->E_above;
+  const bool shell = !p->pmls.empty() || obj || p->H_below || p->E_above || sources_by_launch(p);
   const int lo_skip = p->H_below ? 1 : 0, hi_skip = p->E_above ? 1 : 0;
   const int64_t plane3 = (int64_t)p->ny * p->nz * 3;
   // the products the one-step kernels form per cell, (Courant number x inverse material),
@@ -643,7 +679,11 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
   // the source points outside `inner`, per step; those on plane 0 of a slab open below apart
   ShellSources<T> s1, s2, g1, g2;
   s1.n = s2.n = g1.n = g2.n = 0;
+  // (sources applied apart: by launches of their own after each half step of the cells that the
+  // shell launches step -- all their cells are among those)
+  const bool apart = sources_by_launch(p);
   for (const SourceH& s : p->sources) {
+    if (apart) break;
     const double w0 = waveform(s, q), w1 = waveform(s, q + 1);
     for (int64_t i = 0; i < s.n; ++i) {
       if (m.nsrc >= MAX_STEP_SOURCES) return fail(-1, "internal: too many source points for a whole step");
@@ -776,9 +816,16 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
     };
   if (shell) {
     // first step, in place in A
-    if (pieces & PST_E1_FREE) { if (int rc = half_step(true, false, e1, pb.hole4, EA, HA, EA)) return rc; add(EA, s1); }
+    if (pieces & PST_E1_FREE) {
+      if (int rc = half_step(true, false, e1, pb.hole4, EA, HA, EA)) return rc;
+      add(EA, s1);
+      if (apart) if (int rc = apply_sources_to(p, true, q, EA)) return rc;
+    }
     if ((pieces & PST_E1_GHOST) && lo_skip) { if (int rc = half_step(true, true, e1, pb.hole4, EA, HA, EA)) return rc; add(EA, g1); }
-    if (pieces & PST_H1_FREE) if (int rc = half_step(false, false, h1, pb.hole3, HA, EA, HA)) return rc;
+    if (pieces & PST_H1_FREE) {
+      if (int rc = half_step(false, false, h1, pb.hole3, HA, EA, HA)) return rc;
+      if (apart) if (int rc = apply_sources_to(p, false, q, HA)) return rc;
+    }
     if ((pieces & PST_H1_GHOST) && hi_skip) if (int rc = half_step(false, true, h1, pb.hole3, HA, EA, HA)) return rc;
     if ((pieces & PST_H1_GHOST) && dets.count > 0) {
       // the first step's readings of the other cells: from A, which holds their state after it
@@ -809,9 +856,16 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
   }
   if (shell) {
     // second step, from A into B
-    if (pieces & PST_E2_FREE) { if (int rc = half_step(true, false, m.box, pb.hole2, EA, HA, EB)) return rc; add(EB, s2); }
+    if (pieces & PST_E2_FREE) {
+      if (int rc = half_step(true, false, m.box, pb.hole2, EA, HA, EB)) return rc;
+      add(EB, s2);
+      if (apart) if (int rc = apply_sources_to(p, true, q + 1, EB)) return rc;
+    }
     if ((pieces & PST_E2_GHOST) && lo_skip) { if (int rc = half_step(true, true, m.box, pb.hole2, EA, HA, EB)) return rc; add(EB, g2); }
-    if (pieces & PST_H2_FREE) if (int rc = half_step(false, false, m.box, pb.hole2, HA, EB, HB)) return rc;
+    if (pieces & PST_H2_FREE) {
+      if (int rc = half_step(false, false, m.box, pb.hole2, HA, EB, HB)) return rc;
+      if (apart) if (int rc = apply_sources_to(p, false, q + 1, HB)) return rc;
+    }
     if ((pieces & PST_H2_GHOST) && hi_skip) if (int rc = half_step(false, true, m.box, pb.hole2, HA, EB, HB)) return rc;
     HIPCHK(hipGetLastError());
   }

@@ -148,6 +148,7 @@ double waveform(const SourceH& s, int64_t q) {
 // The E pass of a step filled one row of the objects' curl traces.
 int64_t two_step_launches = 0;
 
+
 int64_t trace_rows_left(const fdtdhip_plan* p) {
   int64_t left = INT64_MAX;
   if (p->trace_cursor < 0) return left;

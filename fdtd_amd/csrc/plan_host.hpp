@@ -222,6 +222,15 @@ int drain_timing(fdtdhip_plan* p);
 int span_begin(fdtdhip_plan* p, size_t& slot);
 int span_end(fdtdhip_plan* p, size_t slot, int what);
 double waveform(const SourceH& s, int64_t q);
+// Whole-step kernels add up to MAX_STEP_SOURCES source points in registers.  Plans with more
+// points, or with a source that sets its box (FDTDHIP_SRC_SET_BOX), apply ALL their sources by
+// launches of their own after the half steps, as fdtdhip_update_E / _H do, in the order of the
+// plan; the box that holds the source cells then belongs to the cells the shell launches step
+// (march_core).  False also where a source keeps a plan from whole steps altogether.
+bool sources_by_launch(const fdtdhip_plan* p);
+// The sources of one half step at time index q applied to the field array F (which need not
+// be the plan's current one), in the order of the plan.
+int apply_sources_to(fdtdhip_plan* p, bool phaseE, int64_t q, void* F);
 void advance_trace_cursor(fdtdhip_plan* p);
 int64_t trace_rows_left(const fdtdhip_plan* p);   // rows the curl traces can still take; huge when none is recorded
 extern int64_t two_step_launches;   // launches of the two-step kernels in this process (diagnostics)

@@ -604,27 +604,44 @@ class Grid:
     _adjoint_second_buffers = True   # (tests switch it off to obtain the two-pass sweep)
 
     @staticmethod
+    def _adjoint_march_forced_env(name):
+        """Whether the environment asks for a marching kernel wherever a plan allows it (tests)."""
+        import os
+
+        return os.environ.get(name) == "2"
+
+    @staticmethod
     def _adjoint_march_forced():
         import os
 
         return os.environ.get("FDTDHIP_ADJ_MARCH") == "2"
 
     def _provide_step_buffers(self, slab=False):
-        """Second E/H (and PML psi_E) buffers that let ``run`` use the fused full-step
-        kernel; allocated once, and only for scenes the native library can fuse (no
+        """Second E/H (and PML psi_E) buffers that let ``run`` use the whole-step kernels;
+        allocated once, and only for scenes the native library can take whole steps on (no
         periodic boundary other than along an axis of one cell, where the copy is the
-        identity; no plane source; few additive source points)."""
+        identity; point, line and plane sources -- on x-slabs and on grids too small to march
+        at most eight additive source points)."""
         if getattr(self, "_step_buffers", None) is not None or (self.Nx != self.Nx_global and not slab):
             return
         points = 0
         for b in self.boundaries:
             if not hasattr(b, "thickness") and self.shape[b.axis] != 1:
                 return
+        from .sources import PlaneSource
+
+        plane = False
         for s in self.sources:
+            if type(s) is PlaneSource:
+                plane = True
+                continue
             if not hasattr(s, "_wave_args"):
                 return
             points += len(s.x) if isinstance(s.x, list) else 1
-        if points > 8:
+        # (more points, or a plane source: applied by launches of their own around the marching
+        # kernels, which large undivided 3-D grids take)
+        if (points > 8 or plane) and (slab or (self.Nx * self.Ny * self.Nz < 1 << 22
+                                               and not self._adjoint_march_forced_env("FDTDHIP_FUSED"))):
             return
         self._step_buffers = (torch.empty_like(self.E.detach()), torch.empty_like(self.H.detach()))
         for b in self.boundaries:

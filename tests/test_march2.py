@@ -380,3 +380,59 @@ def test_random_plans_take_two_steps_per_pass_and_equal_half_steps_bitwise():
         # (nearly every such plan allows pairs; the count keeps the comparison from being empty)
         took = int(done.stdout.rsplit("differ,", 1)[1].split()[0])
         assert took >= count * 3 // 4, done.stdout[-500:]
+
+
+def test_line_and_plane_sources_with_whole_steps_at_the_default_policy(monkeypatch):
+    """Sources of more than eight points and plane sources (which set E and H on their plane,
+    reference fdtd/sources.py:515-525) are applied by launches of their own between the half
+    steps; the box that holds their cells is stepped by the shell launches next to the marching
+    kernels.  A grid of the default policy's size with three PML faces, a line source that starts
+    in a face, a plane source and a point source next to it (their common box is 13 planes of
+    200): two steps per pass, one step per pass and explicit half steps, bit for bit."""
+    monkeypatch.delenv("FDTDHIP_FUSED", raising=False)
+    fdtd.set_backend("hip.float32")
+    shape = (200, 128, 256)
+    lib = _lib.load()
+    rs = np.random.RandomState(3)
+    E0, H0 = 1e-2 * rs.randn(*shape, 3), 1e-2 * rs.randn(*shape, 3)
+
+    def build():
+        g = fdtd.Grid(shape)
+        g.E, g.H = fdtd.backend.array(E0), fdtd.backend.array(H0)
+        g[0:6, :, :] = fdtd.PML()
+        g[:, :, 0:7] = fdtd.PML()
+        g[:, :, -7:] = fdtd.PML()
+        g[3:15, 70, 100] = fdtd.LineSource(period=13)              # starts inside the x-low face
+        g[12, :, :] = fdtd.PlaneSource(period=17, polarization="z")
+        g[14, 75, 110] = fdtd.PointSource(period=9)                # two cells from the plane
+        det = fdtd.LineDetector()
+        g[0:199, 72, 101] = det
+        return g, det
+
+    runs = {}
+    for way, env in (("pairs", None), ("single", "0"), ("half", None)):
+        if env is not None:
+            monkeypatch.setenv("FDTDHIP_MARCH2", env)
+        before = lib.fdtdhip_two_step_launches()
+        g, det = build()
+        if way == "half":
+            for _ in range(11):
+                g.update_E()
+                g.update_H()
+                g.time_steps_passed += 1
+        else:
+            g.run(6, progress_bar=False)
+            g.run(5, progress_bar=False)
+        torch.cuda.synchronize()
+        if env is not None:
+            monkeypatch.delenv("FDTDHIP_MARCH2")
+        taken = lib.fdtdhip_two_step_launches() - before
+        assert taken == (4 if way == "pairs" else 0), (way, taken)
+        if way == "single":      # whole steps by the one-step marching kernel
+            assert _lib.check(lib.fdtdhip_plan_whole_step_kind(g._plan, 0, None, None)) == 2
+        runs[way] = [g.E, g.H, torch.stack(list(det.E)), torch.stack(list(det.H))] + \
+            [t for b in g.boundaries for t in (b._psiE, b._psiH)]
+    assert float(runs["half"][0].abs().max()) > 0
+    for way in ("pairs", "single"):
+        for n, (a, b) in enumerate(zip(runs[way], runs["half"])):
+            assert torch.equal(a, b), (way, n)

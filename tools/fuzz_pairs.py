@@ -38,6 +38,26 @@ def scene(seed):
     sources = [(tuple(int(rs.randint(0, n)) for n in shape), int(rs.randint(4, 20)))
                for _ in range(int(rs.randint(1, 9)))]
     sources = list({c: (c, p) for c, p in sources}.values())
+    # every third scene: a line source of ten points or more and / or a plane source -- sources
+    # that are applied by launches of their own between the half steps, their box stepped by
+    # the shell launches
+    big = []
+    if seed % 3 == 0:
+        if rs.rand() < 0.7:
+            axis = int(rs.randint(3))
+            cell = [int(rs.randint(0, n)) for n in shape]
+            a = int(rs.randint(0, shape[axis] - 12))
+            key = list(cell)
+            key[axis] = slice(a, int(rs.randint(a + 10, min(shape[axis], a + 40))))
+            big.append(("line", tuple(key), int(rs.randint(5, 20))))
+        if rs.rand() < 0.5:
+            axis = int(rs.randint(3))
+            key = [slice(None)] * 3
+            key[axis] = int(rs.randint(0, shape[axis]))
+            pol = "xyz"[(axis + 1 + int(rs.randint(2))) % 3]
+            big.append(("plane", tuple(key), int(rs.randint(5, 20)), pol))
+        if not big:
+            big.append(("line", (slice(3, 15), shape[1] // 2, shape[2] // 2), 9))
     detectors = []
     for _ in range(int(rs.randint(0, 5))):
         axis = int(rs.randint(3))
@@ -52,7 +72,7 @@ def scene(seed):
             key = tuple(slice(min(c, n - 2), min(n - 1, c + int(rs.randint(1, 6)))) for c, n in zip(cell, shape))
             detectors.append(("block", key))
     steps = (int(rs.randint(4, 11)), int(rs.randint(1, 10)))
-    return dict(shape=shape, faces=faces, objects=objects, sources=sources, detectors=detectors,
+    return dict(shape=shape, faces=faces, objects=objects, sources=sources, big=big, detectors=detectors,
                 steps=steps, permittivity=1.0 + rs.rand(), rows=bool(rs.rand() < 0.7), seed=seed)
 
 
@@ -80,6 +100,11 @@ def build(sc, dtype):
         g[tuple(loc)] = fdtd.PML()
     for cell, period in sc["sources"]:
         g[cell] = fdtd.PointSource(period=period)
+    for item in sc["big"]:
+        if item[0] == "line":
+            g[item[1]] = fdtd.LineSource(period=item[2])
+        else:
+            g[item[1]] = fdtd.PlaneSource(period=item[2], polarization=item[3])
     g.dets = []
     for kind, key in sc["detectors"]:
         det = fdtd.LineDetector() if kind == "line" else fdtd.BlockDetector()

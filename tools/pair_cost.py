@@ -1,5 +1,8 @@
 """Time of the two-step kernel and of the launches beside it on 512^3 float32 scenes of growing
-content: vacuum; six PML faces; + two 64^3 objects; + three line detectors (the benchmark's m3).
+content: vacuum; six PML faces; + two 64^3 objects; + three line detectors (the benchmark's m3);
+a line source of 200 points and a plane source over a whole plane instead of the point source
+(applied by launches of their own, their boxes stepped by the shell launches); wall time per
+step beside the kernels' own.
 
     python tools/pair_cost.py [steps]
 """
@@ -16,7 +19,10 @@ from fdtd_amd import _lib  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 fdtd.set_backend("hip.float32")
-for scene in ("vacuum", "pml", "pml+objects", "pml+objects+detectors", "pml(x only)", "pml(y only)", "pml(z only)"):
+import time  # noqa: E402
+
+for scene in ("vacuum", "pml", "pml+objects", "pml+objects+detectors", "pml(x only)", "pml(y only)", "pml(z only)",
+              "vacuum+line source", "pml+line source", "pml+plane source"):
     g = fdtd.Grid((512, 512, 512))
     if scene.startswith("pml"):
         axes = {"pml(x only)": [0], "pml(y only)": [1], "pml(z only)": [2]}.get(scene, [0, 1, 2])
@@ -25,7 +31,12 @@ for scene in ("vacuum", "pml", "pml+objects", "pml+objects+detectors", "pml(x on
             lo[ax], hi[ax] = slice(0, 10), slice(-10, None)
             g[tuple(lo)] = fdtd.PML()
             g[tuple(hi)] = fdtd.PML()
-    g[256, 256, 256] = fdtd.PointSource(period=20)
+    if "line source" in scene:
+        g[156:356, 256, 256] = fdtd.LineSource(period=20)
+    elif "plane source" in scene:
+        g[100, :, :] = fdtd.PlaneSource(period=20, polarization="y")
+    else:
+        g[256, 256, 256] = fdtd.PointSource(period=20)
     if "objects" in scene:
         g[128:192, 128:192, 128:192] = fdtd.AnisotropicObject(permittivity=2.5)
         g[320:384, 128:192, 128:192] = fdtd.AbsorbingObject(permittivity=2.0, conductivity=1e-3)
@@ -41,8 +52,10 @@ for scene in ("vacuum", "pml", "pml+objects", "pml+objects+detectors", "pml(x on
         lib = g._ensure_plan()
         _lib.check(lib.fdtdhip_plan_enable_timing(g._plan, 1))
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
         g.run(steps, progress_bar=False)
         torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / steps * 1e3
     ms, n = (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
     _lib.check(lib.fdtdhip_plan_get_timing_parts(g._plan, ms, n))
     inner = (ctypes.c_int32 * 6)()
@@ -50,6 +63,7 @@ for scene in ("vacuum", "pml", "pml+objects", "pml+objects+detectors", "pml(x on
     cells = (inner[1] - inner[0]) * (inner[3] - inner[2]) * (inner[5] - inner[4]) if two else 0
     print(f"{scene:24s} two-step launches {n[4]:3d} x {ms[4] / max(n[4], 1):.3f} ms over {cells / 1e6:6.1f} M cells "
           f"({ms[4] / max(n[4], 1) / max(cells, 1) * 1e9:.2f} ps per cell and launch); shell {ms[3] / steps:.3f} ms per step; "
-          f"one-step {n[2]} x {ms[2] / max(n[2], 1):.3f}", flush=True)
+          f"one-step {n[2]} x {ms[2] / max(n[2], 1):.3f}; wall {wall:.3f} ms per step = {512 ** 3 / wall / 1e6:.1f} Gcells/s",
+          flush=True)
     del g
     torch.cuda.empty_cache()
