@@ -567,7 +567,11 @@ bool adjoint_pairs_eligible(const fdtdhip_plan* p) {
     return e ? (atoi(e) ? 1 : 0) : -1;
   }();
   if (mode == 0 || adjoint_direct_mode() > 1) return false;
-  if (mode < 0 && p->cells() > (int64_t)(1 << 19)) return false;
+  // (above 2^19 cells the gather derives the difference adjoints of plain cells itself and the
+  // cell pass leaves them out -- adjoint_args; the paired launches know nothing of that, so
+  // they stop there whatever the environment asks: with FDTDHIP_FUSED set they used to go on
+  // and returned wrong gradients on grids of more cells)
+  if (p->cells() > (int64_t)(1 << 19)) return false;
   if (adjoint_rows(p)) return false;   // (never true below 2^19 cells by default; keeps the flat mapping)
   for (const BoundaryRef& b : p->boundaries)
     if (b.kind == 1) return false;
