@@ -12,9 +12,11 @@ namespace fdtdhip {
 
 // ---- fused full step (yee_step.hpp) -------------------------------------------------
 // Usable when nothing has to happen between the two half steps that the fused
-// kernel cannot do itself: no periodic boundary, no hard plane source, no x-slab
-// halo, no curl trace being recorded, at most MAX_STEP_SOURCES additive source points
-// without repeated cells, and the caller has provided the second buffers.
+// kernel cannot do itself: no periodic boundary, no x-slab halo, no curl trace being
+// recorded, at most MAX_STEP_SOURCES additive source points without repeated cells, and the
+// caller has provided the second buffers.  (The marching kernels below take more: open slab
+// faces in stages, recorded runs, and -- on undivided grids -- sources of any number of
+// points and plane sources that are set, applied by launches of their own: sources_by_launch.)
 constexpr int64_t FUSED_AUTO_MAX_CELLS = 1 << 17;
 
 #ifndef FDTDHIP_MARCH_TY32

@@ -267,7 +267,8 @@ int fdtdhip_update_H_post_stage(fdtdhip_plan* plan, int64_t q, int stage);
  * kernel per step, first -> second buffers and back; after the call the state is
  * in the first buffers again.  Contents of the second buffers are scratch.
  * Large 3-D plans with both material arrays proven constant by fdtdhip_plan_scan_materials,
- * at most eight additive source points and at most eight detectors, all
+ * sources that add at points without repeated cells or set a box (more than eight points
+ * and boxes: undivided grids only), at most eight detectors, all
  * of the cell kind, advance TWO steps per pass over memory, in groups of four steps: the
  * state after the odd steps of a group then never exists in memory, except for the cells of
  * PML faces and of the box that holds the objects and the few layers next to them, which
