@@ -539,7 +539,8 @@ int fdtdhip_plan_whole_step_kind(fdtdhip_plan* p, int staged, int32_t core[6], i
   if (!p) return fail(-1, "null plan");
   const FusedKind kind = fused_kind(p, staged != 0);
   int c[6] = {0, p->nx, 0, p->ny, 0, p->nz}, h[6] = {0, 0, 0, 0, 0, 0};
-  const bool shell = !(p->pmls.empty() && p->objs.empty()) || p->H_below || p->E_above || sources_by_launch(p);
+  const bool shell = !(p->pmls.empty() && p->objs.empty()) || p->H_below || p->E_above || sources_by_launch(p) ||
+                     periodic_by_launch(p);
   if (kind == FUSED_MARCH && shell && !march_core(p, c, h)) return fail(-1, "internal: no core box");
   for (int n = 0; n < 6; ++n) {
     if (core) core[n] = c[n];

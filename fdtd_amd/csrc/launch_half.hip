@@ -393,6 +393,28 @@ int sources_to(fdtdhip_plan* p, bool phaseE, int64_t q, T* F) {
 }
 }  // namespace
 
+namespace {
+template <typename T>
+int periodic_to(fdtdhip_plan* p, bool phaseE, T* F) {
+  for (const BoundaryRef& b : p->boundaries) {
+    if (b.kind != 1 || b.idx > 2) continue;
+    const int axis = b.idx;
+    const int n = axis == 0 ? p->nx : (axis == 1 ? p->ny : p->nz);
+    if (n < 2) continue;
+    const int64_t total = p->cells() / n * 3;
+    const int dst = phaseE ? 0 : n - 1, src = phaseE ? n - 1 : 0;
+    hipLaunchKernelGGL((periodic_copy<T>), dim3(blocks_for(total)), dim3(256), 0, p->stream, F, p->nx, p->ny,
+                       p->nz, axis, dst, src);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+int apply_periodic_to(fdtdhip_plan* p, bool phaseE, void* F) {
+  return DISPATCH(p, periodic_to<float>(p, phaseE, (float*)F), periodic_to<double>(p, phaseE, (double*)F));
+}
+
 int apply_sources_to(fdtdhip_plan* p, bool phaseE, int64_t q, void* F) {
   return DISPATCH(p, sources_to<float>(p, phaseE, q, (float*)F), sources_to<double>(p, phaseE, q, (double*)F));
 }

@@ -70,6 +70,12 @@ bool sources_by_launch(const fdtdhip_plan* p) {
   return set_box || points > MAX_STEP_SOURCES;
 }
 
+bool periodic_by_launch(const fdtdhip_plan* p) {
+  for (const BoundaryRef& b : p->boundaries)
+    if (b.kind == 1 && b.idx <= 2) return true;
+  return false;
+}
+
 bool march_core(const fdtdhip_plan* p, int (&core)[6], int (&hole)[6]) {
   BulkArgs<float> b;
   fill_core<float>(p, b);
@@ -78,6 +84,14 @@ bool march_core(const fdtdhip_plan* p, int (&core)[6], int (&hole)[6]) {
   // step of the last plane) waits for the halo exchange: it belongs to the shell
   if (p->H_below) core[0] = std::max(core[0], 1);
   if (p->E_above) core[1] = std::min(core[1], p->nx - 1);
+  // the two planes of a periodic boundary are copied onto each other after each half step:
+  // they belong to the shell as well
+  for (const BoundaryRef& pb : p->boundaries)
+    if (pb.kind == 1 && pb.idx <= 2) {
+      const int n = pb.idx == 0 ? p->nx : (pb.idx == 1 ? p->ny : p->nz);
+      core[2 * pb.idx] = std::max(core[2 * pb.idx], 1);
+      core[2 * pb.idx + 1] = std::min(core[2 * pb.idx + 1], n - 1);
+    }
   // the box the shell launches step inside the core: the objects, and the cells of sources that
   // are applied by launches of their own between the half steps
   int hull[6];
@@ -124,10 +138,14 @@ FusedKind fused_kind(const fdtdhip_plan* p, bool staged, double shell_share) {
   if (halo && !staged) return FUSED_NONE;
   for (const DetH& d : p->dets)
     if (staged && d.below) return FUSED_NONE;   // read between the post pieces and a plane exchange
+  // periodic boundaries: on undivided grids the marching steps take their planes into the shell
+  // and copy by launches of their own; a PML registered after one is corrected after the copy,
+  // which only the half-step path does
+  const bool periodic = periodic_by_launch(p);
   for (const BoundaryRef& b : p->boundaries)
-    if (b.kind == 1) return FUSED_NONE;
+    if (b.kind == 1 && (b.idx > 2 || staged)) return FUSED_NONE;
   for (const PmlH& h : p->pmls)
-    if (!h.psiE_alt) return FUSED_NONE;
+    if (!h.psiE_alt || !h.fused) return FUSED_NONE;
   // sources: point lists that add, up to MAX_STEP_SOURCES points in the kernels' registers;
   // more of them, and boxes that are set, by launches of their own around the marching kernel
   // (not on slabs, whose ghost planes take launches of their own already)
@@ -136,10 +154,10 @@ FusedKind fused_kind(const fdtdhip_plan* p, bool staged, double shell_share) {
     if (!(s.kind == FDTDHIP_SRC_ADD_POINTS && !s.serial) && !(apart && s.kind == FDTDHIP_SRC_SET_BOX))
       return FUSED_NONE;
   if (apart && staged) return FUSED_NONE;
-  const bool cell_ok = !apart && p->nx <= 65535 && (int64_t)p->ny * p->nz < (1ll << 30) &&
+  const bool cell_ok = !apart && !periodic && p->nx <= 65535 && (int64_t)p->ny * p->nz < (1ll << 30) &&
                        p->cells() * 3 < (1ll << 31);   // the kernel's element offsets are 32-bit
   int core[6], hole[6] = {0, 0, 0, 0, 0, 0};
-  const bool whole_grid = p->pmls.empty() && p->objs.empty() && !halo && !apart;   // step_march, no shell
+  const bool whole_grid = p->pmls.empty() && p->objs.empty() && !halo && !apart && !periodic;   // step_march, no shell
   const bool march_ok = (whole_grid || march_core(p, core, hole)) &&
                         p->nz <= 64 * MARCH_MAX_WAVES && p->nx / 16 <= 65535;
   // the cells that take half steps of their own next to the marching kernel
@@ -379,6 +397,8 @@ int launch_march_shell_tiles(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, in
     if (int rc = shell_e(table({{e_lo, c[0], 0, ny, 0, nz}, {c[1], nx, 0, ny, 0, nz}, ylow, yhigh, zlow, zhigh,
                                 {hole[0], hole[1], hole[2], hole[3], hole[4], hole[5]}})))
       return rc;
+    if (periodic_by_launch(p))      // (the copy of the boundary planes, then the sources: the order of a half step)
+      if (int rc = apply_periodic_to(p, true, a.E1)) return rc;
     if (ss_free.n) hipLaunchKernelGGL((shell_sources<T>), dim3(1), dim3(64), 0, p->stream, a.E1, ss_free);
     // (sources applied apart: all their cells lie in the shell or in the box inside the core that
     // the launch above stepped; the marching kernel reads their new E from the second buffer)
@@ -420,6 +440,8 @@ int launch_march_shell_tiles(fdtdhip_plan* p, const StepArgs<T>& a, bool obj, in
       return rc;
   if (stages & ST_H_GHOST)
     if (int rc = shell_h(table({{h_hi, nx, 0, ny, 0, nz}}))) return rc;
+  if ((stages & ST_H_FREE) && periodic_by_launch(p))
+    if (int rc = apply_periodic_to(p, false, a.H1)) return rc;
   if ((stages & ST_H_FREE) && sources_by_launch(p))      // (boxes that are set: H after its half step)
     if (int rc = apply_sources_to(p, false, q, a.H1)) return rc;
   HIPCHK(hipGetLastError());
@@ -520,7 +542,7 @@ int fused_step(fdtdhip_plan* p, int64_t q, FusedKind kind) {
   const int64_t plane = (int64_t)p->ny * p->nz;
   const dim3 grid((unsigned)((plane + 255) / 256), p->nx, 1), block(256);
   const bool pml = a.e.npml > 0, obj = a.e.nobj > 0;
-  if (march && (pml || obj || sources_by_launch(p))) {
+  if (march && (pml || obj || sources_by_launch(p) || periodic_by_launch(p))) {
     if (int rc = launch_march_shell<T>(p, a, obj, ST_ALL, q)) return rc;
   } else {
     size_t slot;
@@ -636,7 +658,8 @@ void grown_hole(const int (&hole)[6], int m, const int (&box)[6], int (&out)[6])
 struct PairBoxes { int inner[6], e1[6], h1[6], hole2[6], hole4[6], hole3[6]; };
 bool pair_boxes(const fdtdhip_plan* p, PairBoxes& b) {
   int core[6] = {0, p->nx, 0, p->ny, 0, p->nz}, hole[6] = {0, 0, 0, 0, 0, 0};
-  if ((!p->pmls.empty() || !p->objs.empty() || p->H_below || p->E_above || sources_by_launch(p)) &&
+  if ((!p->pmls.empty() || !p->objs.empty() || p->H_below || p->E_above || sources_by_launch(p) ||
+       periodic_by_launch(p)) &&
       !march_core(p, core, hole))
     return false;
   if (!(shrunk_core(p, core, 2, b.inner) && shrunk_core(p, core, 3, b.h1) && shrunk_core(p, core, 4, b.e1)))
@@ -667,7 +690,8 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
   const int (&e1)[6] = pb.e1;
   const int (&h1)[6] = pb.h1;
   const bool obj = !p->objs.empty();
-  const bool shell = !p->pmls.empty() || obj || p->H_below || p->E_above || sources_by_launch(p);
+  const bool periodic = periodic_by_launch(p);
+  const bool shell = !p->pmls.empty() || obj || p->H_below || p->E_above || sources_by_launch(p) || periodic;
   const int lo_skip = p->H_below ? 1 : 0, hi_skip = p->E_above ? 1 : 0;
   const int64_t plane3 = (int64_t)p->ny * p->nz * 3;
   // the products the one-step kernels form per cell, (Courant number x inverse material),
@@ -820,12 +844,14 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
     // first step, in place in A
     if (pieces & PST_E1_FREE) {
       if (int rc = half_step(true, false, e1, pb.hole4, EA, HA, EA)) return rc;
+      if (periodic) if (int rc = apply_periodic_to(p, true, EA)) return rc;
       add(EA, s1);
       if (apart) if (int rc = apply_sources_to(p, true, q, EA)) return rc;
     }
     if ((pieces & PST_E1_GHOST) && lo_skip) { if (int rc = half_step(true, true, e1, pb.hole4, EA, HA, EA)) return rc; add(EA, g1); }
     if (pieces & PST_H1_FREE) {
       if (int rc = half_step(false, false, h1, pb.hole3, HA, EA, HA)) return rc;
+      if (periodic) if (int rc = apply_periodic_to(p, false, HA)) return rc;
       if (apart) if (int rc = apply_sources_to(p, false, q, HA)) return rc;
     }
     if ((pieces & PST_H1_GHOST) && hi_skip) if (int rc = half_step(false, true, h1, pb.hole3, HA, EA, HA)) return rc;
@@ -860,12 +886,14 @@ int pair_step(fdtdhip_plan* p, int64_t q, int pieces) {
     // second step, from A into B
     if (pieces & PST_E2_FREE) {
       if (int rc = half_step(true, false, m.box, pb.hole2, EA, HA, EB)) return rc;
+      if (periodic) if (int rc = apply_periodic_to(p, true, EB)) return rc;
       add(EB, s2);
       if (apart) if (int rc = apply_sources_to(p, true, q + 1, EB)) return rc;
     }
     if ((pieces & PST_E2_GHOST) && lo_skip) { if (int rc = half_step(true, true, m.box, pb.hole2, EA, HA, EB)) return rc; add(EB, g2); }
     if (pieces & PST_H2_FREE) {
       if (int rc = half_step(false, false, m.box, pb.hole2, HA, EB, HB)) return rc;
+      if (periodic) if (int rc = apply_periodic_to(p, false, HB)) return rc;
       if (apart) if (int rc = apply_sources_to(p, false, q + 1, HB)) return rc;
     }
     if ((pieces & PST_H2_GHOST) && hi_skip) if (int rc = half_step(false, true, m.box, pb.hole2, HA, EB, HB)) return rc;

@@ -228,6 +228,11 @@ double waveform(const SourceH& s, int64_t q);
 // plan; the box that holds the source cells then belongs to the cells the shell launches step
 // (march_core).  False also where a source keeps a plan from whole steps altogether.
 bool sources_by_launch(const fdtdhip_plan* p);
+// Periodic boundaries whose two planes both lie on this grid: in whole steps their planes are
+// stepped by the shell launches and the copy (reference fdtd/boundaries.py:173-208) is a launch
+// of its own after each half step, before the sources, as in fdtdhip_update_E / _H.
+bool periodic_by_launch(const fdtdhip_plan* p);
+int apply_periodic_to(fdtdhip_plan* p, bool phaseE, void* F);
 // The sources of one half step at time index q applied to the field array F (which need not
 // be the plan's current one), in the order of the plan.
 int apply_sources_to(fdtdhip_plan* p, bool phaseE, int64_t q, void* F);

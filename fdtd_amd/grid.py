@@ -618,16 +618,19 @@ class Grid:
 
     def _provide_step_buffers(self, slab=False):
         """Second E/H (and PML psi_E) buffers that let ``run`` use the whole-step kernels;
-        allocated once, and only for scenes the native library can take whole steps on (no
-        periodic boundary other than along an axis of one cell, where the copy is the
-        identity; point, line and plane sources -- on x-slabs and on grids too small to march
-        at most eight additive source points)."""
+        allocated once, and only for scenes the native library can take whole steps on (point,
+        line and plane sources; on x-slabs and on grids too small to march: at most eight
+        additive source points and no periodic boundary other than along an axis of one cell,
+        where the copy is the identity)."""
         if getattr(self, "_step_buffers", None) is not None or (self.Nx != self.Nx_global and not slab):
             return
         points = 0
+        # (what only the marching kernels of large undivided 3-D grids take: periodic boundaries
+        # along an axis of more than one cell, more than eight source points, plane sources)
+        marching_only = False
         for b in self.boundaries:
             if not hasattr(b, "thickness") and self.shape[b.axis] != 1:
-                return
+                marching_only = True
         from .sources import PlaneSource
 
         plane = False
@@ -640,8 +643,9 @@ class Grid:
             points += len(s.x) if isinstance(s.x, list) else 1
         # (more points, or a plane source: applied by launches of their own around the marching
         # kernels, which large undivided 3-D grids take)
-        if (points > 8 or plane) and (slab or (self.Nx * self.Ny * self.Nz < 1 << 22
-                                               and not self._adjoint_march_forced_env("FDTDHIP_FUSED"))):
+        if (points > 8 or plane or marching_only) and (
+                slab or (self.Nx * self.Ny * self.Nz < 1 << 22
+                         and not self._adjoint_march_forced_env("FDTDHIP_FUSED"))):
             return
         self._step_buffers = (torch.empty_like(self.E.detach()), torch.empty_like(self.H.detach()))
         for b in self.boundaries:

@@ -386,9 +386,10 @@ def test_line_and_plane_sources_with_whole_steps_at_the_default_policy(monkeypat
     """Sources of more than eight points and plane sources (which set E and H on their plane,
     reference fdtd/sources.py:515-525) are applied by launches of their own between the half
     steps; the box that holds their cells is stepped by the shell launches next to the marching
-    kernels.  A grid of the default policy's size with three PML faces, a line source that starts
-    in a face, a plane source and a point source next to it (their common box is 13 planes of
-    200): two steps per pass, one step per pass and explicit half steps, bit for bit."""
+    kernels.  A grid of the default policy's size with three PML faces, a periodic boundary
+    along y with source points on both of its planes, a line source that starts in a face, a
+    plane source and a point source next to it (their common box is 13 planes of 200): two
+    steps per pass, one step per pass and explicit half steps, bit for bit."""
     monkeypatch.delenv("FDTDHIP_FUSED", raising=False)
     fdtd.set_backend("hip.float32")
     shape = (200, 128, 256)
@@ -402,6 +403,12 @@ def test_line_and_plane_sources_with_whole_steps_at_the_default_policy(monkeypat
         g[0:6, :, :] = fdtd.PML()
         g[:, :, 0:7] = fdtd.PML()
         g[:, :, -7:] = fdtd.PML()
+        # (a periodic boundary along y: its two planes are stepped by the shell launches and
+        # copied onto each other by a launch after each half step, before the sources)
+        g[:, 0, :] = fdtd.PeriodicBoundary()
+        # (all sources of this plan share one box: those on the boundary's planes stay near the others)
+        g[10, 0, 100] = fdtd.PointSource(period=7)                 # on the first plane of the boundary
+        g[8, 127, 105] = fdtd.PointSource(period=11)               # ... and on the last
         g[3:15, 70, 100] = fdtd.LineSource(period=13)              # starts inside the x-low face
         g[12, :, :] = fdtd.PlaneSource(period=17, polarization="z")
         g[14, 75, 110] = fdtd.PointSource(period=9)                # two cells from the plane
@@ -431,7 +438,7 @@ def test_line_and_plane_sources_with_whole_steps_at_the_default_policy(monkeypat
         if way == "single":      # whole steps by the one-step marching kernel
             assert _lib.check(lib.fdtdhip_plan_whole_step_kind(g._plan, 0, None, None)) == 2
         runs[way] = [g.E, g.H, torch.stack(list(det.E)), torch.stack(list(det.H))] + \
-            [t for b in g.boundaries for t in (b._psiE, b._psiH)]
+            [t for b in g.boundaries if hasattr(b, "thickness") for t in (b._psiE, b._psiH)]
     assert float(runs["half"][0].abs().max()) > 0
     for way in ("pairs", "single"):
         for n, (a, b) in enumerate(zip(runs[way], runs["half"])):

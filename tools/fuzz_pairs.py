@@ -27,6 +27,12 @@ def scene(seed):
     shape = (int(rs.randint(20, 61)), int(rs.randint(20, 61)), int(rs.randint(64, 161)))
     faces = [(axis, side, int(rs.randint(1, 8))) for axis in range(3) for side in ("low", "high")
              if rs.rand() < 0.6]
+    # every fourth scene: a periodic boundary instead of the PMLs of one axis, registered after
+    # the PMLs of the other axes (a PML registered after it keeps the plan on half steps)
+    periodic = None
+    if seed % 4 == 1:
+        periodic = int(rs.randint(3))
+        faces = [f for f in faces if f[0] != periodic]
     objects = []
     for _ in range(int(rs.randint(0, 4))):
         box = []
@@ -72,7 +78,7 @@ def scene(seed):
             key = tuple(slice(min(c, n - 2), min(n - 1, c + int(rs.randint(1, 6)))) for c, n in zip(cell, shape))
             detectors.append(("block", key))
     steps = (int(rs.randint(4, 11)), int(rs.randint(1, 10)))
-    return dict(shape=shape, faces=faces, objects=objects, sources=sources, big=big, detectors=detectors,
+    return dict(shape=shape, faces=faces, objects=objects, sources=sources, big=big, detectors=detectors, periodic=periodic,
                 steps=steps, permittivity=1.0 + rs.rand(), rows=bool(rs.rand() < 0.7), seed=seed)
 
 
@@ -98,6 +104,10 @@ def build(sc, dtype):
         loc = [slice(None)] * 3
         loc[axis] = slice(0, t) if side == "low" else slice(-t, None)
         g[tuple(loc)] = fdtd.PML()
+    if sc["periodic"] is not None:
+        loc = [slice(None)] * 3
+        loc[sc["periodic"]] = 0
+        g[tuple(loc)] = fdtd.PeriodicBoundary()
     for cell, period in sc["sources"]:
         g[cell] = fdtd.PointSource(period=period)
     for item in sc["big"]:
@@ -116,7 +126,8 @@ def build(sc, dtype):
 def state(g):
     out = [g.E, g.H]
     for b in g.boundaries:
-        out += [b._psiE, b._psiH]
+        if hasattr(b, "thickness"):
+            out += [b._psiE, b._psiH]
     for d in g.dets:
         out += [torch.stack(list(d.E)), torch.stack(list(d.H))]
     return out

@@ -22,15 +22,18 @@ fdtd.set_backend("hip.float32")
 import time  # noqa: E402
 
 for scene in ("vacuum", "pml", "pml+objects", "pml+objects+detectors", "pml(x only)", "pml(y only)", "pml(z only)",
-              "vacuum+line source", "pml+line source", "pml+plane source"):
+              "vacuum+line source", "pml+line source", "pml+plane source", "pml(x, y) + periodic z"):
     g = fdtd.Grid((512, 512, 512))
     if scene.startswith("pml"):
-        axes = {"pml(x only)": [0], "pml(y only)": [1], "pml(z only)": [2]}.get(scene, [0, 1, 2])
+        axes = {"pml(x only)": [0], "pml(y only)": [1], "pml(z only)": [2],
+                "pml(x, y) + periodic z": [0, 1]}.get(scene, [0, 1, 2])
         for ax in axes:
             lo, hi = [slice(None)] * 3, [slice(None)] * 3
             lo[ax], hi[ax] = slice(0, 10), slice(-10, None)
             g[tuple(lo)] = fdtd.PML()
             g[tuple(hi)] = fdtd.PML()
+    if "periodic z" in scene:
+        g[:, :, 0] = fdtd.PeriodicBoundary()
     if "line source" in scene:
         g[156:356, 256, 256] = fdtd.LineSource(period=20)
     elif "plane source" in scene:
