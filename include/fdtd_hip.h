@@ -262,10 +262,11 @@ int fdtdhip_update_H_post_stage(fdtdhip_plan* plan, int64_t q, int stage);
 /* Second buffers for the fused full step (no reference counterpart: the reference
  * always runs the two half steps as separate passes, fdtd/grid.py:267-273).  When
  * E_alt / H_alt (shaped like E / H) and, for every PML, psiE_alt (shaped like psiE)
- * are provided and nothing has to happen between the half steps (no periodic
- * boundary, no plane source, no halo), fdtdhip_run advances pairs of steps with one
- * kernel per step, first -> second buffers and back; after the call the state is
- * in the first buffers again.  Contents of the second buffers are scratch.
+ * are provided, fdtdhip_run advances pairs of steps with one kernel per step (small grids:
+ * no periodic boundary, no plane source, at most eight source points; large 3-D grids: the
+ * cells next to PML faces, objects, periodic boundaries and large sources by launches beside
+ * it), first -> second buffers and back; after the call the state is in the first buffers
+ * again.  Contents of the second buffers are scratch.
  * Large 3-D plans with both material arrays proven constant by fdtdhip_plan_scan_materials,
  * sources that add at points without repeated cells or set a box (more than eight points
  * and boxes: undivided grids only), at most eight detectors, all
