@@ -293,18 +293,20 @@ def test_larger_scenes_adjoint_against_finite_differences():
     assert not bad, bad
 
 
-def operation_sequence_mismatch(seed):
+def operation_sequence_mismatch(seed, big=False):
     """A random scene driven by a random sequence of user operations between runs -- writes
     into the material arrays (in place and by re-binding), into the fields, into an object's
     tensor, components and boundaries registered after steps were taken, fields re-bound to
     new arrays, runs through ``run`` and through
     the half-step entry points -- mirrored on the oracle.  Exercises everything the host
-    layer caches between runs (plan signature, bound pointers, constant-material scan)."""
+    layer caches between runs (plan signature, bound pointers, constant-material scan).
+    big: extents of 40-128 cells and runs of up to 12 steps, so that plans that allow it take
+    whole steps and pairs of steps between the operations (with FDTDHIP_FUSED=2)."""
     from oracle import yee_numpy as orc  # noqa: F401  (the oracle is the checker here)
 
     fdtd.set_backend("hip.float64")
     rs = np.random.RandomState(seed)
-    scene = fuzz_scenes.random_scene(seed)
+    scene = fuzz_scenes.random_scene(seed, big=big)
     grid, made = scenes.build_api(scene, fdtd)
     resolved, arrays = scenes.resolve(scene, grid, made)
     og, omade = scenes.build_oracle(resolved, arrays)
@@ -332,7 +334,7 @@ def operation_sequence_mismatch(seed):
                         "field_rebind"])
         log.append(str(op))
         if op == "run":
-            n = int(rs.randint(1, 7))
+            n = int(rs.randint(1, 13 if big else 7))
             grid.run(n, progress_bar=False)
             og.run(n)
         elif op == "halfsteps":

@@ -1,5 +1,5 @@
 """Random sequences of user operations between runs (the checker of tests/test_fuzz.py over a
-wider range of seeds):  python tools/fuzz_operations.py first count"""
+wider range of seeds):  python tools/fuzz_operations.py first count [big]"""
 import collections
 import os
 import sys
@@ -13,7 +13,7 @@ first, count = int(sys.argv[1]), int(sys.argv[2])
 bad = skipped = 0
 ops = collections.Counter()
 for seed in range(first, first + count):
-    out = test_fuzz.operation_sequence_mismatch(seed)
+    out = test_fuzz.operation_sequence_mismatch(seed, big="big" in sys.argv[3:])
     if out is None:
         skipped += 1
         continue
