@@ -27,7 +27,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29549")
 torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+# (RCCL's stream with high priority, as bench.py asks for it: a plane's send/recv kernel should not
+# queue behind the kernel it is meant to overlap)
+_opts = dist.ProcessGroupNCCL.Options()
+_opts.is_high_priority_stream = os.environ.get("SLAB_PLAIN_PRIORITY") is None
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), pg_options=_opts)
 import fdtd_amd as fdtd  # noqa: E402
 from fdtd_amd.backend import backend as bd  # noqa: E402
 from fdtd_amd.parallel import SlabGrid  # noqa: E402
