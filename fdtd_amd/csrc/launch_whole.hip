@@ -170,7 +170,8 @@ FusedKind fused_kind(const fdtdhip_plan* p, bool staged, double shell_share) {
   if (cell_ok && !staged && p->cells() <= FUSED_AUTO_MAX_CELLS && thin == 1) return FUSED_CELL;
   // (with material arrays to read, the shell's half steps cost more than the marching kernel
   // saves: 512^3 float32, six faces and two 64^3 boxes, 2.44 against 2.26 ms per step)
-  if (!(p->mat_const[0] && p->mat_const[1]) && !(p->pmls.empty() && p->objs.empty())) return FUSED_NONE;
+  if (!(p->mat_const[0] && p->mat_const[1]) && !(p->pmls.empty() && p->objs.empty() && !apart && !periodic))
+    return FUSED_NONE;
   // (PML faces and objects: the shell and the box of the objects take half steps of their
   // own at a third of the marching kernel's rate per cell -- worth it while they are few)
   // (256^3 with six ten-cell faces, 22 % of the cells: float64 0.489 against 0.508 ms per step
