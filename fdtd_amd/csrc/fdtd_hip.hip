@@ -599,6 +599,16 @@ int fdtdhip_step_stage(fdtdhip_plan* p, int64_t q, int stage) {
   return rc;
 }
 
+namespace {
+// The trace / gradient arrays of object `id` changed.  While the table on the device is
+// otherwise current, one object's arrays go with the kernel arguments and the table stays as
+// it is; a second object, or a table that has to be written anyway, takes the upload.
+void rebind_object_arrays(fdtdhip_plan* p, int id) {
+  if (!p->obj_dirty && (p->ovr_obj < 0 || p->ovr_obj == id)) p->ovr_obj = id;
+  else p->obj_dirty = true;
+}
+}  // namespace
+
 int fdtdhip_plan_set_object_trace(fdtdhip_plan* p, int id, void* trace, int64_t capacity) {
   if (!p) return fail(-1, "null plan");
   if (id < 0 || id >= (int)p->objs.size()) return fail(-1, "unknown object id");
@@ -607,7 +617,7 @@ int fdtdhip_plan_set_object_trace(fdtdhip_plan* p, int id, void* trace, int64_t 
     return fail(-1, "curl traces exist for anisotropic objects only");
   p->objs[id].trace = trace;
   p->objs[id].trace_capacity = trace ? capacity : 0;
-  p->obj_dirty = true;
+  rebind_object_arrays(p, id);
   p->trace_cursor = -1;
   for (const ObjH& o : p->objs)
     if (o.trace && o.trace_capacity > 0) p->trace_cursor = 0;
@@ -632,7 +642,7 @@ int fdtdhip_plan_set_object_grad(fdtdhip_plan* p, int id, void* grad) {
   if (!p) return fail(-1, "null plan");
   if (id < 0 || id >= (int)p->objs.size()) return fail(-1, "unknown object id");
   p->objs[id].grad = grad;
-  p->obj_dirty = true;
+  rebind_object_arrays(p, id);
   return 0;
 }
 

@@ -44,6 +44,7 @@ int adjoint_args(fdtdhip_plan* p, bool phaseE, T* lamE, T* lamH, T* work, AdjArg
   a.npml = (int)p->pmls.size();
   a.nobj = phaseE ? (int)p->objs.size() : 0;
   a.obj = (const ObjK<T>*)p->obj_table;
+  fill_object_override<T>(p, a);
   a.trace_step = phaseE ? p->trace_cursor : -1;
   for (const PmlH& h : p->pmls)
     if (!(phaseE ? h.lamE : h.lamH)) return fail(-1, "PML adjoint arrays not set");
@@ -747,6 +748,7 @@ int adjoint_run_noalloc(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH)
   void* const obj_table = p->obj_table;
   const size_t obj_table_bytes = p->obj_table_bytes;
   const bool obj_dirty = p->obj_dirty, pml_dirty = p->pml_dirty;
+  const int ovr_obj = p->ovr_obj;
   void* const pml_tables = p->pml_tables;
   void* const adj_work = p->adj_work;
   const int64_t adj_work_bytes = p->adj_work_bytes;
@@ -763,6 +765,7 @@ int adjoint_run_noalloc(fdtdhip_plan* p, int64_t nsteps, void* lamE, void* lamH)
   p->obj_table_bytes = obj_table_bytes;
   p->pml_tables = pml_tables;
   p->obj_dirty = obj_dirty;             // the plan's own tables are as current as they were
+  p->ovr_obj = ovr_obj;
   p->pml_dirty = pml_dirty;
   p->adj_work = adj_work;
   p->adj_work_bytes = adj_work_bytes;

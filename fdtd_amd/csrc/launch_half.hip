@@ -84,6 +84,7 @@ int bulk_launch(fdtdhip_plan* p, bool phaseE, int x0, int x1) {
   a.npml = (int)p->pmls.size();
   a.nobj = phaseE ? (int)p->objs.size() : 0;
   a.obj = (const ObjK<T>*)p->obj_table;
+  fill_object_override<T>(p, a);
   a.trace_step = phaseE ? p->trace_cursor : -1;
   if (int rc = sync_pml_tables<T>(p)) return rc;
   a.pml = pml_table<T>(p, phaseE ? TAB_E : TAB_H);

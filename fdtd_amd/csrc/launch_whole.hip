@@ -474,6 +474,7 @@ int step_args(fdtdhip_plan* p, int64_t q, bool march, StepArgs<T>& a) {
     b.npml = (int)p->pmls.size();
     b.nobj = phaseE ? (int)p->objs.size() : 0;
     b.obj = (const ObjK<T>*)p->obj_table;
+    fill_object_override<T>(p, b);
     b.trace_step = phaseE ? p->trace_cursor : -1;   // the owner lane records the curl
     fill_core<T>(p, b);
     fill_material<T>(p, phaseE, b);

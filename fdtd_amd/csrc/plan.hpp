@@ -61,6 +61,12 @@ struct BulkArgs {
   int npml;
   int nobj;
   const ObjK<T>* obj;
+  // One object's trace and gradient arrays may travel with the kernel arguments instead of in
+  // the table (load_obj): a tape that records one step per node binds new ones for every node,
+  // and a table upload per node costs more than the step's launch.  ovr_obj: its index, or -1.
+  int ovr_obj;
+  T* ovr_trace;
+  T* ovr_grad;
   int64_t trace_step;  // row of the objects' curl traces to write (forward) / read (adjoint); -1: none
   const PmlK<T>* pml;  // device table of npml descriptors (read with scalar loads, one at a time)
   int mat_const;       // 1: `mat` was scanned and holds `bg` in every cell outside the object
@@ -91,6 +97,9 @@ struct AdjArgs {
   int npml;
   int nobj;
   const ObjK<T>* obj;
+  int ovr_obj;         // as in BulkArgs
+  T* ovr_trace;
+  T* ovr_grad;
   int64_t trace_step;
   const PmlK<T>* pml;  // device table; psi -> adjoint of the memory variables
   // x-slabs: the slab continues below plane 0 / above plane nx-1 on a neighbour rank, so the
@@ -109,5 +118,16 @@ struct AdjArgs {
   // wavefront reads the descriptor of a face only if one of its cells lies in that face
   int face_axis[MAX_PML], face_lo[MAX_PML], face_hi[MAX_PML];
 };
+
+// Descriptor `o` of the object table, with the arrays that travel with the arguments in place.
+template <typename T, typename Args>
+__device__ __forceinline__ ObjK<T> load_obj(const Args& a, int o) {
+  ObjK<T> O = a.obj[o];
+  if (o == a.ovr_obj) {
+    O.trace = a.ovr_trace;
+    O.grad = a.ovr_grad;
+  }
+  return O;
+}
 
 }  // namespace fdtdhip

@@ -33,6 +33,7 @@ int release_tables(fdtdhip_plan* p) {
   p->sources.clear();
   p->dets.clear();
   p->obj_dirty = false;
+  p->ovr_obj = -1;
   p->mat_const[0] = p->mat_const[1] = false;
   p->detmap = nullptr;  // was in `owned`
   p->detmap_state = 0;

@@ -182,6 +182,8 @@ struct fdtdhip_plan {
   void* obj_table = nullptr;  // device ObjK<T>[]
   size_t obj_table_bytes = 0;
   bool obj_dirty = false;
+  // the one object whose trace / gradient arrays travel with the kernel arguments (BulkArgs::ovr_obj)
+  int ovr_obj = -1;
   // device tables of PML descriptors, one per use (see PmlTab); rebuilt when dirty
   void* pml_tables = nullptr;
   bool pml_dirty = true;
@@ -289,7 +291,17 @@ int sync_obj_table(fdtdhip_plan* p) {
     if (int rc = upload_table(p, p->obj_table, tab.data(), bytes)) return rc;
   }
   p->obj_dirty = false;
+  p->ovr_obj = -1;      // (the table holds every array again)
   return 0;
+}
+
+// The object whose trace / gradient arrays go with the kernel arguments (plan.hpp: load_obj).
+template <typename T, typename Args>
+void fill_object_override(const fdtdhip_plan* p, Args& a) {
+  const bool on = p->ovr_obj >= 0 && p->ovr_obj < (int)p->objs.size();
+  a.ovr_obj = on ? p->ovr_obj : -1;
+  a.ovr_trace = on ? (T*)p->objs[p->ovr_obj].trace : nullptr;
+  a.ovr_grad = on ? (T*)p->objs[p->ovr_obj].grad : nullptr;
 }
 
 // Which PML descriptor table a kernel reads: the two half steps in place, the E half

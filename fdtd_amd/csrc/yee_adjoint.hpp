@@ -145,7 +145,7 @@ __device__ __forceinline__ void adj_material(const AdjArgs<T>& a, int64_t c3, in
                       k >= a.hull[4] && k < a.hull[5];
     if (a.nobj && __any(near))
       for (int o = 0; o < a.nobj; ++o) {
-        const ObjK<T> O = a.obj[o];
+        const ObjK<T> O = load_obj<T>(a, o);
         covered |= i >= O.x0 && i < O.x1 && j >= O.y0 && j < O.y1 && k >= O.z0 && k < O.z1;
       }
 #pragma unroll
@@ -307,7 +307,7 @@ __device__ __forceinline__ bool adj_E_cell(const AdjArgs<T>& a, int i, int j, in
   T g[3] = {0, 0, 0};
   if (adj_any_obj(a, i, j, k))
   for (int o = a.nobj - 1; o >= 0; --o) {
-    const ObjK<T> O = a.obj[o];
+    const ObjK<T> O = load_obj<T>(a, o);
     if (i < O.x0 || i >= O.x1 || j < O.y0 || j >= O.y1 || k < O.z0 || k >= O.z1) continue;
     const int64_t oc =
         ((int64_t)(i - O.x0) * (O.y1 - O.y0) + (j - O.y0)) * (O.z1 - O.z0) + (k - O.z0);

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void adj_rescale_absorbing(AdjArgs<T> a, T* la
   T lam[3] = {lamE[c3], lamE[c3 + 1], lamE[c3 + 2]};
   bool changed = false;
   for (int o = a.nobj - 1; o >= 0; --o) {
-    const ObjK<T> O = a.obj[o];
+    const ObjK<T> O = load_obj<T>(a, o);
     if (O.kind != 1 || i < O.x0 || i >= O.x1 || j < O.y0 || j >= O.y1 || k < O.z0 || k >= O.z1) continue;
     const int64_t oc =
         ((int64_t)(i - O.x0) * (O.y1 - O.y0) + (j - O.y0)) * (O.z1 - O.z0) + (k - O.z0);

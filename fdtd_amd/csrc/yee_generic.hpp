@@ -192,7 +192,7 @@ __device__ __forceinline__ void finish_E(const BulkArgs<T>& a, int i, int j, int
 
   if (HAS_OBJ && __any(in_hull(a, i, j, k))) {
     for (int o = 0; o < a.nobj; ++o) {
-      const ObjK<T> O = a.obj[o];
+      const ObjK<T> O = load_obj<T>(a, o);
       apply_object<T, HAS_MOD>(a, O, i, j, k, cu, e, hs, store);
     }
   }
@@ -228,7 +228,7 @@ __device__ __forceinline__ void cell_material(const BulkArgs<T>& a, int64_t c3, 
     bool covered = false;
     if (HAS_OBJ && __any(in_hull(a, i, j, k)))
       for (int o = 0; o < a.nobj; ++o) {
-        const ObjK<T> O = a.obj[o];
+        const ObjK<T> O = load_obj<T>(a, o);
         covered |= i >= O.x0 && i < O.x1 && j >= O.y0 && j < O.y1 && k >= O.z0 && k < O.z1;
       }
 #pragma unroll

@@ -206,7 +206,7 @@ __device__ __forceinline__ void new_E_cells(const StepArgs<T>& a, StepCell<T> (&
     bool covered[STEP_CELLS] = {false, false, false, false};
     if (obj_near)
       for (int o = 0; o < A.nobj; ++o) {
-        const ObjK<T> O = A.obj[o];
+        const ObjK<T> O = load_obj<T>(A, o);
 #pragma unroll
         for (int q = 0; q < STEP_CELLS; ++q)
           covered[q] |= c[q].i >= O.x0 && c[q].i < O.x1 && c[q].j >= O.y0 && c[q].j < O.y1 &&
@@ -233,7 +233,7 @@ __device__ __forceinline__ void new_E_cells(const StepArgs<T>& a, StepCell<T> (&
 
   if (obj_near)
     for (int o = 0; o < A.nobj; ++o) {
-      const ObjK<T> O = A.obj[o];
+      const ObjK<T> O = load_obj<T>(A, o);
 #pragma unroll
       for (int q = 0; q < STEP_CELLS; ++q)
         if (c[q].live)
