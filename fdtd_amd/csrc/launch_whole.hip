@@ -594,13 +594,14 @@ constexpr double MARCH2_OUTSIDE_SHARE = 0.4;   // cells outside the inner box: a
 
 namespace {
 
-// The core box of a plan shrunk by `m` cells on every side where a shell lies (a side that
-// coincides with a face of the grid has none).  False if nothing is left.
-bool shrunk_core(const fdtdhip_plan* p, const int (&core)[6], int m, int (&box)[6]) {
+// The core box of a plan shrunk by `lo` cells on every low side and `hi` cells on every high
+// side where a shell lies (a side that coincides with a face of the grid has none).  False if
+// nothing is left.
+bool shrunk_core(const fdtdhip_plan* p, const int (&core)[6], int lo, int hi, int (&box)[6]) {
   const int n[3] = {p->nx, p->ny, p->nz};
   for (int ax = 0; ax < 3; ++ax) {
-    box[2 * ax] = core[2 * ax] > 0 ? core[2 * ax] + m : 0;
-    box[2 * ax + 1] = core[2 * ax + 1] < n[ax] ? core[2 * ax + 1] - m : n[ax];
+    box[2 * ax] = core[2 * ax] > 0 ? core[2 * ax] + lo : 0;
+    box[2 * ax + 1] = core[2 * ax + 1] < n[ax] ? core[2 * ax + 1] - hi : n[ax];
     if (box[2 * ax + 1] - box[2 * ax] < 1) return false;
   }
   return true;
@@ -642,21 +643,30 @@ Shell shell_around(const fdtdhip_plan* p, const int (&c)[6], int x_from, int x_t
 }
 
 // `hole` grown by m cells on every side and cut to `box`; all zeros if nothing is left (or there is no hole).
-void grown_hole(const int (&hole)[6], int m, const int (&box)[6], int (&out)[6]) {
+void grown_hole(const int (&hole)[6], int lo, int hi, const int (&box)[6], int (&out)[6]) {
   bool any = hole[1] > hole[0];
   for (int ax = 0; ax < 3 && any; ++ax) {
-    out[2 * ax] = std::max(hole[2 * ax] - m, box[2 * ax]);
-    out[2 * ax + 1] = std::min(hole[2 * ax + 1] + m, box[2 * ax + 1]);
+    out[2 * ax] = std::max(hole[2 * ax] - lo, box[2 * ax]);
+    out[2 * ax + 1] = std::min(hole[2 * ax + 1] + hi, box[2 * ax + 1]);
     any = out[2 * ax + 1] > out[2 * ax];
   }
   if (!any)
     for (int n = 0; n < 6; ++n) out[n] = 0;
 }
 
-// The boxes of a pair of steps: inner (two-step kernel) and the boxes outside which the first
-// step's E and H half steps run; with objects, the box that holds them (clipped to the core)
-// grown by two, four and three cells: an island inside each of those boxes that belongs to the
-// cells outside it.  False: the plan has no room for them.
+// The boxes of a pair of steps.  The E half step reads H of a cell and of its neighbours
+// BELOW it (x - e), the H half step E of the cell and of its neighbours ABOVE (reference
+// fdtd/grid.py:42-49, 67-74), so what a cell's state after two steps depends on reaches one
+// cell down and two cells up along every axis:
+//   inner  the cells the two-step kernel stores: their boxes [-1, +2]^3 are plain cells, i.e. the
+//          core shrunk by 1 on its low sides and by 2 on its high sides; O = the cells outside it;
+//   h1     the first step's H half step runs outside it: O and the layer of `inner` under each of
+//          its high faces, whose H' the second E half step of the cells above them reads;
+//   e1     the first step's E half step runs outside it: the cells of the H half step and the
+//          ones above each of them -- one layer of `inner` more on the low sides.
+// With objects (or sources applied by launch) the box that holds them, grown by the mirror
+// image of those margins and clipped, is an island inside each box that belongs to the cells
+// outside it.  False: the plan has no room for them.
 struct PairBoxes { int inner[6], e1[6], h1[6], hole2[6], hole4[6], hole3[6]; };
 bool pair_boxes(const fdtdhip_plan* p, PairBoxes& b) {
   int core[6] = {0, p->nx, 0, p->ny, 0, p->nz}, hole[6] = {0, 0, 0, 0, 0, 0};
@@ -664,11 +674,12 @@ bool pair_boxes(const fdtdhip_plan* p, PairBoxes& b) {
        periodic_by_launch(p)) &&
       !march_core(p, core, hole))
     return false;
-  if (!(shrunk_core(p, core, 2, b.inner) && shrunk_core(p, core, 3, b.h1) && shrunk_core(p, core, 4, b.e1)))
+  if (!(shrunk_core(p, core, 1, 2, b.inner) && shrunk_core(p, core, 1, 3, b.h1) &&
+        shrunk_core(p, core, 2, 3, b.e1)))
     return false;
-  grown_hole(hole, 2, b.inner, b.hole2);
-  grown_hole(hole, 3, b.h1, b.hole3);
-  grown_hole(hole, 4, b.e1, b.hole4);
+  grown_hole(hole, 2, 1, b.inner, b.hole2);
+  grown_hole(hole, 3, 1, b.h1, b.hole3);
+  grown_hole(hole, 3, 2, b.e1, b.hole4);
   return true;
 }
 
