@@ -241,7 +241,7 @@ def roofline(grid, cells, es, timing, mask, steps, workload):
         pass_ms = (ms[4] + ms[3]) / n[4]
         roof.update({
             "kernel": ("two-step marching kernel (E and H advanced twice in one pass)" if inner == cells else
-                       "two-step marching kernel over the cells three or more away from PML faces, objects and "
+                       "two-step marching kernel over the cells two or three layers away from PML faces, objects and "
                        "open slab faces; two steps of half-step launches over the others"),
             "kernel_cells": inner, "grid_cells": cells,
             "shell_ms_per_step": round(ms[3] / steps, 4),

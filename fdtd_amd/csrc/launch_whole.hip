@@ -575,17 +575,16 @@ int staged_step(fdtdhip_plan* p, int64_t q, int stage) {
 
 // ---- two steps per pass (yee_march2.hpp) ------------------------------------------------
 // Whole grids without PML faces: one launch of the two-step kernel.  Plans with PML faces:
-// the two-step kernel advances the box `inner` = the PML-free core shrunk by two cells on every
-// side that has a shell (its cells and the two layers around them are plain, so it needs the
-// state before the pair and nothing else), and the cells outside `inner` take the two steps
-// one after the other with the shell kernels of the one-step march (yee_shell.hpp):
+// the two-step kernel advances the box `inner` (pair_boxes: the PML-free core shrunk by one
+// cell on its low sides and by two on its high sides, so that everything the cells' two steps
+// depend on is plain and it needs the state before the pair and nothing else), and the cells
+// outside `inner` take the two steps one after the other with the shell kernels of the one-step
+// march (yee_shell.hpp):
 //   1. two-step kernel over `inner`:            (E, H)(n) of A  ->  (E, H)(n+2) of B
-//   2. first step of the others, in place in A (nothing reads A's old values any more):
-//        E half step over the cells outside `inner` shrunk by two more cells,
-//        H half step over the cells outside `inner` shrunk by one
-//      (the extra layers belong to `inner`: their state after the first step, which the
-//      two-step kernel kept in registers, is what the second step of the cells next to `inner`
-//      reads; evaluated as the plain cells they are)
+//   2. first step of the others, in place in A (nothing reads A's old values any more), over a
+//      few layers of `inner` as well (pair_boxes: e1, h1): their state after the first step,
+//      which the two-step kernel kept in registers, is what the second step of the cells next
+//      to `inner` reads; evaluated as the plain cells they are
 //   3. second step of the cells outside `inner`, from A into B: E half step, then H half
 //      step, which reads the new E of `inner`'s outermost cells from B.
 // Same operations on the same operands as four half steps everywhere: bitwise equal.
@@ -686,8 +685,8 @@ bool pair_boxes(const fdtdhip_plan* p, PairBoxes& b) {
 // The pieces of a pair of steps.  On an x-slab two planes wait for a neighbour's plane in every
 // step -- plane 0 in the E half step, the last plane in the H half step -- and take launches of
 // their own (..._GHOST), so that a caller can place the rest around the four plane exchanges
-// of the pair.  The two-step kernel reads no ghost plane at all (its box keeps three planes
-// away from an open face) and comes first: the first step of the others overwrites what it reads.
+// of the pair.  The two-step kernel reads no ghost plane at all (its box keeps two planes from an
+// open low face and three from an open high one) and comes first: the first step of the others overwrites what it reads.
 enum { PST_INNER = 1, PST_E1_FREE = 2, PST_E1_GHOST = 4, PST_H1_FREE = 8, PST_H1_GHOST = 16,
        PST_E2_FREE = 32, PST_E2_GHOST = 64, PST_H2_FREE = 128, PST_H2_GHOST = 256, PST_ALL = 511 };
 

@@ -398,7 +398,7 @@ class SlabGrid(Grid):
     def _pair_of_steps(self, eng, q, cur, alt):
         """Steps ``q`` and ``q + 1`` from the buffers ``cur`` = (E, H) into ``alt`` in eight pieces
         around the four plane exchanges (``fdtdhip_pair_stage``).  The two-step kernel takes the
-        cells three or more planes away from the slab's open faces (and from PMLs) in one pass
+        cells a few planes away from the slab's open faces (and from PMLs) in one pass
         and needs no neighbour's plane; the others take the two steps one after the other, the
         first in place in ``cur``, each plane exchange hidden behind the launches that do not
         wait for it."""

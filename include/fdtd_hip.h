@@ -278,7 +278,8 @@ int fdtdhip_update_H_post_stage(fdtdhip_plan* plan, int64_t q, int stage);
 int fdtdhip_plan_set_step_buffers(fdtdhip_plan* plan, void* E_alt, void* H_alt);
 /* Whether fdtdhip_run would advance this plan two steps per pass (1) or not (0), and the box
  * {x0,x1,y0,y1,z0,z1} the two-step kernel covers (inner, may be NULL): the whole grid, or with
- * PML faces the PML-free box shrunk by two cells on every side with a face; the cells outside it
+ * PML faces the PML-free box shrunk by one cell on every low side and by two on every high side
+ * with a face (the reach of the Yee stencil over two steps); the cells outside it
  * (and those of the objects' box grown by two layers, which lies inside it) take the two steps
  * one after the other (no reference counterpart; benchmarks use it to
  * price the kernels). */
@@ -290,8 +291,8 @@ int64_t fdtdhip_two_step_launches(void);
  * exchanges (`staged` != 0 above asks whether the plan can take them), the counterpart of
  * fdtdhip_step_stage for two steps per pass.  With the fields in the first buffers A and the
  * second buffers B:
- *   stage 0  the two-step kernel over the inner box (A -> B; it keeps three planes away from an
- *            open face and reads no ghost plane), then the first step's E half step of the cells
+ *   stage 0  the two-step kernel over the inner box (A -> B; it keeps two planes from an open low
+ *            face, three from an open high one, and reads no ghost plane), then the first step's E half step of the cells
  *            outside it except plane 0, in place in A          -- while H_below (step q) travels;
  *   stage 1  E half step of plane 0 (reads H_below).  Its new (Ey, Ez), in A, go to the rank below;
  *   stage 2  the first step's H half step except the last plane, in place in A;
