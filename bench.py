@@ -139,14 +139,14 @@ def build_workload(fdtd, name, n_slabs=1, rank=0, group=None):
 def slab_planes(name, per_rank, n_slabs):
     """x planes of every rank.  The two end slabs of a simulation with PMLs on its x faces
     carry ten planes of PML cells each, which cost more than plain ones (measured on one GPU,
-    tools/slab_step_cost.py, two steps per pass: the first slab of m4 2.38 ms per step against
-    2.25 ms for an interior one, i.e. 14.4 planes' worth): with three or more ranks the end
-    slabs hand 14.4 (n - 2) / n planes each to the interior ones (eleven on eight ranks), so
+    tools/slab_step_cost.py, two steps per pass: the first slab of m4 2.265 ms per step against
+    2.127 ms for an interior one, i.e. 16.6 planes' worth): with three or more ranks the end
+    slabs hand 16.6 (n - 2) / n planes each to the interior ones (twelve on eight ranks), so
     that every rank's step takes about the same time.  The simulation and its total number of cells stay
     what they are."""
     if name != "m4" or n_slabs < 3:
         return None
-    trim = round(14.4 * (n_slabs - 2) / n_slabs)
+    trim = round(16.6 * (n_slabs - 2) / n_slabs)
     planes = [per_rank] * n_slabs
     planes[0] -= trim
     planes[-1] -= trim
