@@ -176,7 +176,11 @@ FusedKind fused_kind(const fdtdhip_plan* p, bool staged, double shell_share) {
   // own at a third of the marching kernel's rate per cell -- worth it while they are few)
   // (256^3 with six ten-cell faces, 22 % of the cells: float64 0.489 against 0.508 ms per step
   // in a bare loop and no difference in the benchmark, float32 0.256 against 0.235)
-  if (march_ok && p->nz >= 128 && p->ny >= 64 && p->nx >= 64 && p->cells() >= (1ll << 22) &&
+  // (size: 2^22 cells in float32 -- 160^3 with six ten-cell faces runs at 52.4 Gcells/s by half
+  // steps and 44.5 two steps per pass, 192^3 at 61 either way --, 4.0 M in float64, where 160^3
+  // gains: 29.0 -> 33.2, and 144^3 does not: 29.3 -> 28.9)
+  const int64_t min_cells = p->dtype == FDTDHIP_F32 ? (1ll << 22) : 4000000;
+  if (march_ok && p->nz >= 128 && p->ny >= 64 && p->nx >= 64 && p->cells() >= min_cells &&
       (double)shell_cells <= shell_share * (double)p->cells())
     return FUSED_MARCH;
   return FUSED_NONE;
