@@ -179,7 +179,12 @@ FusedKind fused_kind(const fdtdhip_plan* p, bool staged, double shell_share) {
   // (size: 2^22 cells in float32 -- 160^3 with six ten-cell faces runs at 52.4 Gcells/s by half
   // steps and 44.5 two steps per pass, 192^3 at 61 either way --, 4.0 M in float64, where 160^3
   // gains: 29.0 -> 33.2, and 144^3 does not: 29.3 -> 28.9)
-  const int64_t min_cells = p->dtype == FDTDHIP_F32 ? (1ll << 22) : 4000000;
+  // Whole grids (no shell at all) in float64 from 2.0 M: 128^3 40.0 -> 49.6, 112^3 32.7 -> 35.1,
+  // 96^3 28.2 -> 23.4; in float32 144^3 loses (70.5 -> 64.2) and 160^3 gains (67.3 -> 70.8).
+  // (With faces float32 is a close call up to 200^3 -- 176^3 55.8 by half steps against 51.3,
+  // 192^3 66.9 / 60.9, 200^3 56.7 / 62.8, 224^3 58.9 / 75.8: rows that are whole multiples of 64
+  // cells favour the half-step kernels.)
+  const int64_t min_cells = p->dtype == FDTDHIP_F32 ? (1ll << 22) : (whole_grid ? 2000000 : 4000000);
   if (march_ok && p->nz >= 128 && p->ny >= 64 && p->nx >= 64 && p->cells() >= min_cells &&
       (double)shell_cells <= shell_share * (double)p->cells())
     return FUSED_MARCH;
