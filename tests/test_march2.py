@@ -388,11 +388,11 @@ def test_line_and_plane_sources_with_whole_steps_at_the_default_policy(monkeypat
     steps; the box that holds their cells is stepped by the shell launches next to the marching
     kernels.  A grid of the default policy's size with three PML faces, a periodic boundary
     along y with source points on both of its planes, a line source that starts in a face, a
-    plane source and a point source next to it (their common box is 13 planes of 200): two
+    plane source and a point source next to it (their common box is 13 planes of 232): two
     steps per pass, one step per pass and explicit half steps, bit for bit."""
     monkeypatch.delenv("FDTDHIP_FUSED", raising=False)
     fdtd.set_backend("hip.float32")
-    shape = (200, 128, 256)
+    shape = (232, 128, 256)
     lib = _lib.load()
     rs = np.random.RandomState(3)
     E0, H0 = 1e-2 * rs.randn(*shape, 3), 1e-2 * rs.randn(*shape, 3)
@@ -413,7 +413,7 @@ def test_line_and_plane_sources_with_whole_steps_at_the_default_policy(monkeypat
         g[12, :, :] = fdtd.PlaneSource(period=17, polarization="z")
         g[14, 75, 110] = fdtd.PointSource(period=9)                # two cells from the plane
         det = fdtd.LineDetector()
-        g[0:199, 72, 101] = det
+        g[0:231, 72, 101] = det
         return g, det
 
     runs = {}
